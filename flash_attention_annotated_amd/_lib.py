@@ -1,0 +1,148 @@
+"""ctypes binding of the C-ABI in include/fa_fwd.h (libfa_fwd_gfx950.so).
+
+The shared library is the product: there is no Python/CPU fallback.  If it is
+missing or the GPU is absent, every compute entry point raises.
+"""
+import ctypes
+import os
+import subprocess
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_NAME = "libfa_fwd_gfx950.so"
+LIB_PATH = os.path.join(_HERE, LIB_NAME)
+CSRC = os.path.join(_HERE, "csrc")
+INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
+
+FA_ABI_VERSION = 1
+FA_DTYPE_FP16, FA_DTYPE_BF16, FA_DTYPE_FP8_E4M3 = 0, 1, 2
+
+# every symbol include/fa_fwd.h declares (tests check the .so exports all of them)
+EXPORTED_SYMBOLS = (
+    "fa_fwd",
+    "fa_fwd_validate",
+    "fa_strerror",
+    "fa_fwd_params_size",
+    "fa_abi_version",
+    "fa_fwd_tile_shape",
+    "fa_set_default_variant",
+)
+
+
+class FaFwdParams(ctypes.Structure):
+    """Field-for-field mirror of `struct fa_fwd_params` (include/fa_fwd.h)."""
+
+    _fields_ = [
+        ("abi_version", ctypes.c_uint32),
+        ("struct_size", ctypes.c_uint32),
+        ("q", ctypes.c_void_p),
+        ("k", ctypes.c_void_p),
+        ("v", ctypes.c_void_p),
+        ("o", ctypes.c_void_p),
+        ("softmax_lse", ctypes.c_void_p),
+        ("q_batch_stride", ctypes.c_int64),
+        ("q_row_stride", ctypes.c_int64),
+        ("q_head_stride", ctypes.c_int64),
+        ("k_batch_stride", ctypes.c_int64),
+        ("k_row_stride", ctypes.c_int64),
+        ("k_head_stride", ctypes.c_int64),
+        ("v_batch_stride", ctypes.c_int64),
+        ("v_row_stride", ctypes.c_int64),
+        ("v_head_stride", ctypes.c_int64),
+        ("o_batch_stride", ctypes.c_int64),
+        ("o_row_stride", ctypes.c_int64),
+        ("o_head_stride", ctypes.c_int64),
+        ("b", ctypes.c_int32),
+        ("seqlen_q", ctypes.c_int32),
+        ("seqlen_k", ctypes.c_int32),
+        ("h", ctypes.c_int32),
+        ("h_k", ctypes.c_int32),
+        ("d", ctypes.c_int32),
+        ("total_q", ctypes.c_int32),
+        ("dtype", ctypes.c_int32),
+        ("cu_seqlens_q", ctypes.c_void_p),
+        ("cu_seqlens_k", ctypes.c_void_p),
+        ("seqused_q", ctypes.c_void_p),
+        ("seqused_k", ctypes.c_void_p),
+        ("softmax_scale", ctypes.c_float),
+        ("softcap", ctypes.c_float),
+        ("is_causal", ctypes.c_int32),
+        ("window_size_left", ctypes.c_int32),
+        ("window_size_right", ctypes.c_int32),
+        ("q_descale", ctypes.c_void_p),
+        ("k_descale", ctypes.c_void_p),
+        ("v_descale", ctypes.c_void_p),
+        ("q_descale_batch_stride", ctypes.c_int64),
+        ("q_descale_head_stride", ctypes.c_int64),
+        ("k_descale_batch_stride", ctypes.c_int64),
+        ("k_descale_head_stride", ctypes.c_int64),
+        ("v_descale_batch_stride", ctypes.c_int64),
+        ("v_descale_head_stride", ctypes.c_int64),
+        ("kernel_variant", ctypes.c_int32),
+        ("reserved0", ctypes.c_int32),
+    ]
+
+
+def build(force=False, verbose=False):
+    """Compile csrc/ for gfx950 into the in-tree shared library (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, "fa_fwd_api.hip")]
+    deps = srcs + [os.path.join(CSRC, "fa_fwd_kernel.h"), os.path.join(INCLUDE, "fa_fwd.h")]
+    if not force and os.path.exists(LIB_PATH):
+        if os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps):
+            return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        hipcc = "hipcc"
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-I", INCLUDE, "-I", CSRC, *srcs, "-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load():
+    """dlopen the library and declare prototypes.  Raises if the library is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_NAME} is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"(expected at {LIB_PATH}); there is no CPU fallback")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.fa_fwd.argtypes = [ctypes.POINTER(FaFwdParams), ctypes.c_void_p]
+    lib.fa_fwd.restype = ctypes.c_int
+    lib.fa_fwd_validate.argtypes = [ctypes.POINTER(FaFwdParams)]
+    lib.fa_fwd_validate.restype = ctypes.c_int
+    lib.fa_strerror.argtypes = [ctypes.c_int]
+    lib.fa_strerror.restype = ctypes.c_char_p
+    lib.fa_fwd_params_size.argtypes = []
+    lib.fa_fwd_params_size.restype = ctypes.c_uint32
+    lib.fa_abi_version.argtypes = []
+    lib.fa_abi_version.restype = ctypes.c_uint32
+    lib.fa_fwd_tile_shape.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                      ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
+    lib.fa_fwd_tile_shape.restype = ctypes.c_int
+    lib.fa_set_default_variant.argtypes = [ctypes.c_int32]
+    lib.fa_set_default_variant.restype = None
+    if lib.fa_fwd_params_size() != ctypes.sizeof(FaFwdParams):
+        raise RuntimeError("fa_fwd_params layout mismatch between include/fa_fwd.h and _lib.FaFwdParams")
+    if lib.fa_abi_version() != FA_ABI_VERSION:
+        raise RuntimeError("fa_fwd ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def strerror(status):
+    return load().fa_strerror(status).decode()
+
+
+def new_params():
+    p = FaFwdParams()
+    p.abi_version = FA_ABI_VERSION
+    p.struct_size = ctypes.sizeof(FaFwdParams)
+    return p

@@ -1,0 +1,183 @@
+// fa_fwd_api.hip — C-ABI entry points declared in include/fa_fwd.h.
+//
+// Host-side role of mha_fwd / mha_varlen_fwd (csrc/flash_attn/flash_api.cpp:350-512, 514-755),
+// set_params_fprop (:26-159) and run_mha_fwd (:243-255): validate, fill the kernel params,
+// pick the instantiation, launch on the caller's stream.  No allocation, no synchronisation.
+#include "fa_fwd.h"
+#include "fa_fwd_kernel.h"
+
+#include <atomic>
+#include <cmath>
+
+namespace {
+
+std::atomic<int> g_default_variant{0};
+
+int head_dim_tile(int d) {
+    if (d <= 64) return 64;
+    if (d <= 128) return 128;
+    return 256;
+}
+
+template <typename T, int D, int NWAVES, bool SOFTCAP>
+int launch(const fa::KParams &kp, hipStream_t stream) {
+    constexpr int smem = fa::smem_bytes<D, NWAVES>();
+    auto kernel = fa::fwd_kernel<T, D, NWAVES, SOFTCAP>;
+    static std::atomic<bool> attr_set{false};
+    if (smem > 65536 && !attr_set.load(std::memory_order_acquire)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) {
+            (void)hipGetLastError();
+            return FA_ERR_LAUNCH;
+        }
+        attr_set.store(true, std::memory_order_release);
+    }
+    hipLaunchKernelGGL(kernel, dim3(kp.num_tiles), dim3(NWAVES * 64), smem, stream, kp);
+    if (hipGetLastError() != hipSuccess) return FA_ERR_LAUNCH;
+    return FA_OK;
+}
+
+template <typename T, int D>
+int dispatch_variant(const fa::KParams &kp, bool softcap, int variant, hipStream_t stream) {
+    // variant 0/1: 8 waves x 32 rows (BLOCK_M 256); variant 2: 4 waves x 32 rows (BLOCK_M 128).
+    // D = 256 needs the 512-register budget of one wave per SIMD, so it always takes the 4-wave shape.
+    if constexpr (D == 256) {
+        if (softcap) return launch<T, D, 4, true>(kp, stream);
+        return launch<T, D, 4, false>(kp, stream);
+    } else {
+        if (variant == 2) {
+            if (softcap) return launch<T, D, 4, true>(kp, stream);
+            return launch<T, D, 4, false>(kp, stream);
+        }
+        if (softcap) return launch<T, D, 8, true>(kp, stream);
+        return launch<T, D, 8, false>(kp, stream);
+    }
+}
+
+template <typename T>
+int dispatch_hdim(const fa::KParams &kp, bool softcap, int variant, hipStream_t stream) {
+    switch (head_dim_tile(kp.d)) {
+        case 64: return dispatch_variant<T, 64>(kp, softcap, variant, stream);
+        case 128: return dispatch_variant<T, 128>(kp, softcap, variant, stream);
+        default: return dispatch_variant<T, 256>(kp, softcap, variant, stream);
+    }
+}
+
+int block_m_of(int variant, int d) { return (variant == 2 || head_dim_tile(d) == 256) ? 128 : 256; }
+
+}  // namespace
+
+extern "C" {
+
+uint32_t fa_fwd_params_size(void) { return (uint32_t)sizeof(fa_fwd_params); }
+uint32_t fa_abi_version(void) { return FA_ABI_VERSION; }
+void fa_set_default_variant(int32_t variant) { g_default_variant.store(variant); }
+
+const char *fa_strerror(int status) {
+    switch (status) {
+        case FA_OK: return "ok";
+        case FA_ERR_NULL_POINTER: return "a required tensor pointer is NULL";
+        case FA_ERR_BAD_DTYPE: return "FlashAttention only support fp16 and bf16 data type";
+        case FA_ERR_BAD_HEAD_DIM:
+            return "FlashAttention forward only supports head dimension at most 256, and head_size must be a multiple of 8";
+        case FA_ERR_BAD_HEADS: return "Number of heads in key/value must divide number of heads in query";
+        case FA_ERR_BAD_SHAPE: return "batch size must be positive and sequence lengths non-negative";
+        case FA_ERR_BAD_STRIDE: return "tensor base pointers and row/head/batch strides must keep rows 16-byte aligned";
+        case FA_ERR_UNSUPPORTED: return "feature not supported by this build of the forward";
+        case FA_ERR_LAUNCH: return "kernel launch failed";
+        case FA_ERR_BAD_ABI: return "fa_fwd_params abi_version/struct_size mismatch";
+        case FA_ERR_NO_DEVICE: return "no gfx950 device";
+        default: return "unknown status";
+    }
+}
+
+int fa_fwd_tile_shape(int32_t d, int32_t dtype, int32_t is_causal, int32_t *block_m, int32_t *block_n) {
+    (void)dtype;
+    (void)is_causal;
+    if (d <= 0 || d > 256 || d % 8) return FA_ERR_BAD_HEAD_DIM;
+    if (block_m) *block_m = block_m_of(g_default_variant.load(), d);
+    if (block_n) *block_n = fa::BLOCK_N;
+    return FA_OK;
+}
+
+int fa_fwd_validate(const fa_fwd_params *p) {
+    if (!p) return FA_ERR_NULL_POINTER;
+    if (p->abi_version != FA_ABI_VERSION || p->struct_size != sizeof(fa_fwd_params)) return FA_ERR_BAD_ABI;
+    if (p->dtype != FA_DTYPE_FP16 && p->dtype != FA_DTYPE_BF16) return FA_ERR_BAD_DTYPE;  // fp8: not built yet
+    if (p->b <= 0 || p->h <= 0 || p->h_k <= 0 || p->seqlen_q < 0 || p->seqlen_k < 0) return FA_ERR_BAD_SHAPE;
+    if (p->d <= 0 || p->d > 256 || p->d % 8 != 0) return FA_ERR_BAD_HEAD_DIM;
+    if (p->h % p->h_k != 0) return FA_ERR_BAD_HEADS;
+    if ((p->cu_seqlens_q == nullptr) != (p->cu_seqlens_k == nullptr)) return FA_ERR_BAD_SHAPE;
+    if (p->cu_seqlens_q && p->total_q < 0) return FA_ERR_BAD_SHAPE;
+    const bool empty = (p->seqlen_q == 0) || (p->cu_seqlens_q && p->total_q == 0);
+    if (!empty) {
+        if (!p->q || !p->o || !p->softmax_lse) return FA_ERR_NULL_POINTER;
+        if (p->seqlen_k > 0 && (!p->k || !p->v)) return FA_ERR_NULL_POINTER;
+    }
+    // 16-byte vector loads/stores: bases and strides must keep every row 16-byte aligned
+    const int64_t strides[] = {p->q_row_stride, p->q_head_stride, p->k_row_stride, p->k_head_stride,
+                               p->v_row_stride, p->v_head_stride, p->o_row_stride, p->o_head_stride};
+    for (int64_t s : strides)
+        if (s % 8 != 0) return FA_ERR_BAD_STRIDE;
+    if (!p->cu_seqlens_q) {
+        const int64_t bs[] = {p->q_batch_stride, p->k_batch_stride, p->v_batch_stride, p->o_batch_stride};
+        for (int64_t s : bs)
+            if (s % 8 != 0) return FA_ERR_BAD_STRIDE;
+    }
+    const void *ptrs[] = {p->q, p->k, p->v, p->o};
+    for (const void *ptr : ptrs)
+        if (reinterpret_cast<uintptr_t>(ptr) % 16 != 0) return FA_ERR_BAD_STRIDE;
+    if (p->softcap < 0.f || std::isnan(p->softcap) || std::isnan(p->softmax_scale)) return FA_ERR_BAD_SHAPE;
+    return FA_OK;
+}
+
+int fa_fwd(const fa_fwd_params *p, void *stream_) {
+    const int st = fa_fwd_validate(p);
+    if (st != FA_OK) return st;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+
+    int variant = p->kernel_variant ? p->kernel_variant : g_default_variant.load();
+    if (variant < 0 || variant > 2) variant = 0;
+    const int block_m = block_m_of(variant, p->d);
+
+    fa::KParams kp{};
+    kp.q = p->q; kp.k = p->k; kp.v = p->v; kp.o = p->o; kp.lse = p->softmax_lse;
+    kp.cu_seqlens_q = p->cu_seqlens_q; kp.cu_seqlens_k = p->cu_seqlens_k;
+    kp.seqused_q = p->seqused_q; kp.seqused_k = p->seqused_k;
+    kp.q_batch_stride = p->q_batch_stride; kp.q_row_stride = p->q_row_stride; kp.q_head_stride = p->q_head_stride;
+    kp.k_batch_stride = p->k_batch_stride; kp.k_row_stride = p->k_row_stride; kp.k_head_stride = p->k_head_stride;
+    kp.v_batch_stride = p->v_batch_stride; kp.v_row_stride = p->v_row_stride; kp.v_head_stride = p->v_head_stride;
+    kp.o_batch_stride = p->o_batch_stride; kp.o_row_stride = p->o_row_stride; kp.o_head_stride = p->o_head_stride;
+    kp.b = p->b; kp.seqlen_q = p->seqlen_q; kp.seqlen_k = p->seqlen_k; kp.h = p->h; kp.h_k = p->h_k; kp.d = p->d;
+    kp.total_q = p->total_q;
+    kp.h_ratio = p->h / p->h_k;
+    kp.num_m_blocks = (p->seqlen_q + block_m - 1) / block_m;
+    const int64_t tiles = (int64_t)kp.num_m_blocks * p->h * p->b;
+    if (tiles == 0) return FA_OK;  // nothing to compute (seqlen_q == 0)
+    if (tiles > 0x7fffffff) return FA_ERR_BAD_SHAPE;
+    kp.num_tiles = (int32_t)tiles;
+
+    // window normalisation: csrc/flash_attn/flash_api.cpp:396-402
+    int wl = p->window_size_left, wr = p->window_size_right;
+    if (wl >= p->seqlen_k) wl = -1;
+    if (wr >= p->seqlen_k) wr = -1;
+    if (p->is_causal) wr = 0;
+    kp.window_left = wl;
+    kp.window_right = wr;
+
+    const bool softcap = p->softcap > 0.f;
+    constexpr float kLog2e = 1.4426950408889634f;
+    if (softcap) {  // set_params_fprop csrc/flash_attn/flash_api.cpp:103-117
+        kp.softcap_pre = p->softmax_scale / p->softcap;
+        kp.scale = p->softcap;
+        kp.scale_log2 = p->softcap * kLog2e;
+    } else {
+        kp.softcap_pre = 0.f;
+        kp.scale = p->softmax_scale;
+        kp.scale_log2 = p->softmax_scale * kLog2e;
+    }
+
+    if (p->dtype == FA_DTYPE_BF16) return dispatch_hdim<__bf16>(kp, softcap, variant, stream);
+    return dispatch_hdim<_Float16>(kp, softcap, variant, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,420 @@
+// fa_fwd_kernel.h — gfx950 (CDNA4) FlashAttention forward mainloop, hand-written HIP.
+//
+// Roles re-derived for MI355X (not translated) from the reference's forward:
+//   mainloop   hopper/mainloop_fwd_sm90_tma_gmma_ws.hpp:589-891,953-1352,
+//              csrc/flash_attn/src/flash_fwd_kernel.h:51-494      -> fwd_kernel() tile loop
+//   softmax    hopper/softmax.h:92-168, csrc/flash_attn/src/softmax.h:128-187 -> online_softmax_tile()
+//   mask       hopper/mask.h:44-162, csrc/flash_attn/src/mask.h:111-212        -> apply_mask()
+//   block      hopper/block.h:14-59, csrc/flash_attn/src/block_info.h:12-45     -> SeqInfo / n-range
+//   epilogue   hopper/epilogue_fwd.hpp:213-402                                  -> store_output()
+//   scheduler  hopper/tile_scheduler.hpp:36-136,218-363                         -> decode_tile() (XCD-aware)
+//
+// Design (wave64, MFMA 32x32x16, 160 KiB LDS):
+//   * workgroup = NWAVES waves, each wave owns 32 query rows (BLOCK_M = 32*NWAVES), K/V tile = 64 keys.
+//   * scores are computed TRANSPOSED, S^T = K.Q^T, so one lane owns one query row: the 32x32 f32
+//     accumulator has the query on the lane and the keys in its 16 registers.  Row max / row sum are
+//     in-register reductions plus one v_permlane32_swap between the two lane halves.
+//   * O is accumulated transposed as well, O^T = V^T.P^T: the S^T accumulator registers, rounded to
+//     bf16/fp16, ARE the B operand of that product (no LDS round trip, no shuffles), and the online
+//     softmax rescale is one per-lane scalar.
+//   * V^T fragments come from a row-major V tile in LDS through ds_read_b64_tr_b16 (hardware transpose).
+//   * K and V tiles are double-buffered in LDS; global loads for tile n+1 are issued before the
+//     compute of tile n and written to LDS after it (one barrier per tile).
+//   * LDS images are XOR-swizzled so that both the ds_read_b128 row reads (K) and the transposed
+//     reads (V) are bank-conflict free.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fa {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+// Device-side copy of the fields of fa_fwd_params the kernel needs (kernarg, by value).
+struct KParams {
+    const void *q, *k, *v;
+    void *o;
+    float *lse;
+    const int32_t *cu_seqlens_q, *cu_seqlens_k, *seqused_q, *seqused_k;
+    int64_t q_batch_stride, q_row_stride, q_head_stride;
+    int64_t k_batch_stride, k_row_stride, k_head_stride;
+    int64_t v_batch_stride, v_row_stride, v_head_stride;
+    int64_t o_batch_stride, o_row_stride, o_head_stride;
+    int32_t b, seqlen_q, seqlen_k, h, h_k, d, total_q;
+    int32_t h_ratio;       // h / h_k
+    int32_t num_m_blocks;  // ceil(seqlen_q / BLOCK_M)
+    int32_t num_tiles;     // num_m_blocks * h * b
+    int32_t window_left, window_right;  // <0 unbounded; causal => right = 0
+    float scale;           // softmax_scale (softcap: the softcap value)
+    float scale_log2;      // scale * log2(e)
+    float softcap_pre;     // softmax_scale / softcap (0 when softcap is off)
+};
+
+template <typename T> struct Elem;
+template <> struct Elem<__bf16> {
+    static __device__ __forceinline__ f32x16 mma(u32x4 a, u32x4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+        bf16x2 v = {(__bf16)lo, (__bf16)hi};  // v_cvt_pk_bf16_f32, round-to-nearest-even
+        return __builtin_bit_cast(uint32_t, v);
+    }
+};
+template <> struct Elem<_Float16> {
+    static __device__ __forceinline__ f32x16 mma(u32x4 a, u32x4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+        f16x2 v = {(_Float16)lo, (_Float16)hi};  // round-to-nearest-even
+        return __builtin_bit_cast(uint32_t, v);
+    }
+};
+
+constexpr int BLOCK_N = 64;  // keys per K/V tile
+
+// Byte offset of 16-byte chunk `ch` of row `row` inside a [rows][D] 16-bit LDS tile.
+// The XOR keeps (a) ds_read_b128 of 16 lanes reading the same chunk of 16 rows distinct mod 16 and
+// (b) ds_read_b64_tr_b16 of 4 consecutive rows x 64 bytes on distinct banks.
+template <int D>
+__device__ __forceinline__ int lds_off(int row, int ch) {
+    if constexpr (D == 64) {
+        const int g = (((row >> 1) & 1) << 2) | ((row >> 2) & 3);
+        return row * 128 + 16 * (ch ^ g);
+    } else {
+        const int g = ((row & 3) << 2) | ((row >> 2) & 3);
+        return row * (D * 2) + 16 * (ch ^ g);
+    }
+}
+
+__device__ __forceinline__ float half_swap_max(float x) {
+    // max over the two lane halves (lane l <-> l^32); one v_permlane32_swap
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float half_swap_sum(float x) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+__device__ __forceinline__ float fast_tanh(float x) {
+    // tanh(x) = 1 - 2 / (exp(2x) + 1); role of cutlass::fast_tanh (hopper/utils.h:635-641)
+    const float e = __builtin_amdgcn_exp2f(x * 2.885390081777927f);  // exp(2x)
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+}
+
+template <typename T, int D, int NWAVES, bool SOFTCAP>
+__global__ __launch_bounds__(NWAVES * 64) void fwd_kernel(const KParams p) {
+    constexpr int NT = NWAVES * 64;
+    constexpr int BLOCK_M = NWAVES * 32;
+    constexpr int KSTEPS = D / 16;             // k-steps of the QK^T product
+    constexpr int DBLOCKS = D / 32;            // 32-wide blocks of the head dim (O^T row blocks)
+    constexpr int CH_PER_ROW = D / 8;          // 16-byte chunks per row
+    constexpr int TILE_BYTES = BLOCK_N * D * 2;
+    constexpr int CHUNKS = BLOCK_N * CH_PER_ROW;
+    constexpr int LD_PER_THREAD = CHUNKS / NT;
+    static_assert(CHUNKS % NT == 0, "tile must divide over the workgroup");
+    constexpr int O_ROW_BYTES = D * 2 + 16;    // padded epilogue row (16-byte aligned)
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // [K0 | K1 | V0 | V1]; the epilogue reuses the whole region as NWAVES x [32][O_ROW_BYTES]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31;
+    const int hh = lane >> 5;
+
+    // ---- tile scheduler: XCD-aware linear tile id -> (m_block, head, batch) --------------------
+    // Workgroups are dealt round-robin over the 8 XCDs; give each XCD a contiguous chunk of the
+    // (batch, head, m_block) list so workgroups sharing one K/V head share one L2.
+    int tile;
+    {
+        const int wg = blockIdx.x;
+        const int nwg = p.num_tiles;
+        const int xcd = wg & 7, slot = wg >> 3;
+        const int q8 = nwg >> 3, r8 = nwg & 7;
+        tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+    }
+    const int mi = tile % p.num_m_blocks;
+    const int bh = tile / p.num_m_blocks;
+    const int m_block = p.num_m_blocks - 1 - mi;  // heaviest (causal) blocks first
+    const int head = bh % p.h;
+    const int batch = bh / p.h;
+    const int kv_head = head / p.h_ratio;
+
+    // ---- sequence bookkeeping (BlockInfo / SeqlenInfo role) --------------------------------------
+    int sq, sk;
+    int64_t q_base, k_base, v_base, o_base, lse_base;
+    if (p.cu_seqlens_q) {
+        const int q0 = p.cu_seqlens_q[batch];
+        sq = p.seqused_q ? p.seqused_q[batch] : p.cu_seqlens_q[batch + 1] - q0;
+        q_base = (int64_t)q0 * p.q_row_stride;
+        o_base = (int64_t)q0 * p.o_row_stride;
+        lse_base = (int64_t)head * p.total_q + q0;
+    } else {
+        sq = p.seqused_q ? p.seqused_q[batch] : p.seqlen_q;
+        q_base = (int64_t)batch * p.q_batch_stride;
+        o_base = (int64_t)batch * p.o_batch_stride;
+        lse_base = ((int64_t)batch * p.h + head) * p.seqlen_q;
+    }
+    if (p.cu_seqlens_k) {
+        const int k0 = p.cu_seqlens_k[batch];
+        sk = p.seqused_k ? p.seqused_k[batch] : p.cu_seqlens_k[batch + 1] - k0;
+        k_base = (int64_t)k0 * p.k_row_stride;
+        v_base = (int64_t)k0 * p.v_row_stride;
+    } else {
+        sk = p.seqused_k ? p.seqused_k[batch] : p.seqlen_k;
+        k_base = (int64_t)batch * p.k_batch_stride;
+        v_base = (int64_t)batch * p.v_batch_stride;
+    }
+    const int row_lo = m_block * BLOCK_M;
+    if (row_lo >= sq) return;  // whole workgroup: nothing to do (varlen / padded grid)
+
+    const T *qp = (const T *)p.q + q_base + (int64_t)head * p.q_head_stride;
+    const T *kp = (const T *)p.k + k_base + (int64_t)kv_head * p.k_head_stride;
+    const T *vp = (const T *)p.v + v_base + (int64_t)kv_head * p.v_head_stride;
+    T *op = (T *)p.o + o_base + (int64_t)head * p.o_head_stride;
+
+    // ---- key range of this row block (BlockMN::get_n_block_min_max role) ------------------------
+    const int shift = sk - sq;  // bottom-right aligned masks
+    const int row_hi = min(sq, row_lo + BLOCK_M);
+    int key_hi = sk, key_lo = 0;
+    if (p.window_right >= 0) key_hi = min(sk, row_hi + shift + p.window_right);
+    if (p.window_left >= 0) key_lo = max(0, row_lo + shift - p.window_left);
+    const int n_min = key_lo / BLOCK_N;
+    const int n_max = key_hi > 0 ? (key_hi + BLOCK_N - 1) / BLOCK_N : 0;
+
+    const int wrow = row_lo + wave * 32;          // first row of this wave
+    const int my_row = wrow + r;                  // the query row this lane owns
+    const bool wave_active = wrow < sq;
+
+    // ---- Q fragments: B operand of S^T = K.Q^T; lane (r,hh) holds Q[row r][16ks + 8hh .. +8] ------
+    u32x4 qf[KSTEPS];
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+        const int d0 = ks * 16 + hh * 8;
+        u32x4 val = {0, 0, 0, 0};
+        if (my_row < sq && d0 < p.d) val = *(const u32x4 *)(qp + (int64_t)my_row * p.q_row_stride + d0);
+        qf[ks] = val;
+    }
+
+    // ---- accumulators --------------------------------------------------------------------------
+    f32x16 o_acc[DBLOCKS];
+#pragma unroll
+    for (int db = 0; db < DBLOCKS; ++db)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o_acc[db][i] = 0.f;
+    float m_run = -INFINITY;  // running row max (unscaled scores), same in both lane halves
+    float l_run = 0.f;        // running row sum, PARTIAL per lane half (combined in the epilogue)
+
+    // ---- K/V staging -------------------------------------------------------------------------
+    u32x4 kreg[LD_PER_THREAD], vreg[LD_PER_THREAD];
+    auto load_tile = [&](int n) {
+#pragma unroll
+        for (int i = 0; i < LD_PER_THREAD; ++i) {
+            const int c = tid + i * NT;
+            const int row = c / CH_PER_ROW, ch = c % CH_PER_ROW;
+            const int key = n * BLOCK_N + row;
+            u32x4 kv = {0, 0, 0, 0}, vv = {0, 0, 0, 0};
+            if (key < sk && ch * 8 < p.d) {
+                kv = *(const u32x4 *)(kp + (int64_t)key * p.k_row_stride + ch * 8);
+                vv = *(const u32x4 *)(vp + (int64_t)key * p.v_row_stride + ch * 8);
+            }
+            kreg[i] = kv;
+            vreg[i] = vv;
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < LD_PER_THREAD; ++i) {
+            const int c = tid + i * NT;
+            const int row = c / CH_PER_ROW, ch = c % CH_PER_ROW;
+            const int off = lds_off<D>(row, ch);
+            *(u32x4 *)(smem + buf * TILE_BYTES + off) = kreg[i];
+            *(u32x4 *)(smem + (2 + buf) * TILE_BYTES + off) = vreg[i];
+        }
+    };
+
+    // lane-constant pieces of the LDS read addresses
+    const int i16 = lane & 15;           // lane inside its 16-lane group
+    const int g1 = (lane >> 4) & 1;      // which 16-column half of a 32-wide d block
+
+    if (n_min < n_max) {
+        load_tile(n_min);
+        store_tile(0);
+    }
+    __syncthreads();
+
+    for (int n = n_min; n < n_max; ++n) {
+        const int cur = (n - n_min) & 1;
+        const bool has_next = (n + 1 < n_max);
+        if (has_next) load_tile(n + 1);
+
+        const int k0 = n * BLOCK_N;
+        // wave-uniform tile classification (3-phase split of hopper/block.h:106-135, decided per tile)
+        bool skip = !wave_active;
+        bool need_mask = (k0 + BLOCK_N > sk);
+        if (p.window_right >= 0) {
+            skip = skip || (k0 > wrow + 31 + shift + p.window_right);
+            need_mask = need_mask || (k0 + BLOCK_N - 1 > wrow + shift + p.window_right);
+        }
+        if (p.window_left >= 0) {
+            skip = skip || (k0 + BLOCK_N - 1 < wrow + shift - p.window_left);
+            need_mask = need_mask || (k0 < wrow + 31 + shift - p.window_left);
+        }
+
+        if (!skip) {
+            const char *kbuf = smem + cur * TILE_BYTES;
+            const char *vbuf = smem + (2 + cur) * TILE_BYTES;
+
+            // ---- S^T = K.Q^T : two 32-key blocks ------------------------------------------------
+            f32x16 s[2];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { s[0][i] = 0.f; s[1][i] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+                const int off = lds_off<D>(r, 2 * ks + hh);  // swizzle depends on row & 15 only
+                const u32x4 kf0 = *(const u32x4 *)(kbuf + off);
+                const u32x4 kf1 = *(const u32x4 *)(kbuf + off + 32 * D * 2);
+                s[0] = Elem<T>::mma(kf0, qf[ks], s[0]);
+                s[1] = Elem<T>::mma(kf1, qf[ks], s[1]);
+            }
+
+            if constexpr (SOFTCAP) {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) s[kb][i] = fast_tanh(s[kb][i] * p.softcap_pre);
+            }
+
+            // ---- mask (boundary tiles only) -----------------------------------------------------
+            if (need_mask) {
+                int lim_hi = sk;  // exclusive
+                int lim_lo = 0;   // inclusive
+                if (p.window_right >= 0) lim_hi = min(sk, my_row + shift + p.window_right + 1);
+                if (p.window_left >= 0) lim_lo = max(0, my_row + shift - p.window_left);
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int key = k0 + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                        if (key >= lim_hi || key < lim_lo) s[kb][i] = -INFINITY;
+                    }
+            }
+
+            // ---- online softmax (per lane = per query row) ----------------------------------------
+            float mx = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+            for (int i = 1; i < 16; ++i) mx = fmaxf(mx, fmaxf(s[0][i], s[1][i]));
+            mx = half_swap_max(mx);
+            const float m_new = fmaxf(m_run, mx);
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;  // fully masked so far
+            const float mc = m_use * p.scale_log2;
+            if (__any(m_new > m_run)) {  // wave-uniform; bit-identical to always rescaling
+                const float alpha = __builtin_amdgcn_exp2f(m_run * p.scale_log2 - mc);
+                l_run *= alpha;
+#pragma unroll
+                for (int db = 0; db < DBLOCKS; ++db)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) o_acc[db][i] *= alpha;
+            }
+            m_run = m_new;
+            float psum = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float pv = __builtin_amdgcn_exp2f(s[kb][i] * p.scale_log2 - mc);
+                    s[kb][i] = pv;
+                    psum += pv;
+                }
+            l_run += psum;
+
+            // ---- P^T fragments: accumulator registers ARE the B operand of O^T += V^T.P^T ------------
+            u32x4 pf[4];
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const int kb = st >> 1, b8 = (st & 1) * 8;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pf[st][j] = Elem<T>::pack2(s[kb][b8 + 2 * j], s[kb][b8 + 2 * j + 1]);
+            }
+
+            // ---- O^T += V^T.P^T ----------------------------------------------------------------
+            // element j of lane half hh of k-step st is key 16st + 8(j>>2) + 4hh + (j&3)
+#pragma unroll
+            for (int db = 0; db < DBLOCKS; ++db) {
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    u32x4 vf;
+#pragma unroll
+                    for (int j2 = 0; j2 < 2; ++j2) {
+                        const int row = 16 * st + 8 * j2 + 4 * hh + (i16 >> 2);
+                        const int ch = db * 4 + 2 * g1 + ((i16 >> 1) & 1);
+                        const int off = lds_off<D>(row, ch) + 8 * (i16 & 1);
+                        const s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) s16x4 *)(vbuf + off));
+                        const u32x2 t2 = __builtin_bit_cast(u32x2, t);
+                        vf[2 * j2] = t2[0];
+                        vf[2 * j2 + 1] = t2[1];
+                    }
+                    o_acc[db] = Elem<T>::mma(vf, pf[st], o_acc[db]);
+                }
+            }
+        }
+
+        if (has_next) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: normalise, LSE, O^T regs -> LDS -> coalesced rows -------------------------------
+    // (the loop's last barrier has retired every K/V read, so the region can be reused)
+    const float l_tot = half_swap_sum(l_run);
+    const bool empty = (l_tot == 0.f) || (l_tot != l_tot);
+    const float inv = empty ? 1.f : 1.f / l_tot;
+    if (wave_active) {
+        if (hh == 0 && my_row < sq) {
+            // csrc/flash_attn/src/softmax.h:178-180: +inf for rows with no valid key
+            p.lse[lse_base + my_row] = empty ? INFINITY : m_run * p.scale + __logf(l_tot);
+        }
+        char *obuf = smem + wave * (32 * O_ROW_BYTES);
+#pragma unroll
+        for (int db = 0; db < DBLOCKS; ++db)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                u32x2 w;
+                w[0] = Elem<T>::pack2(o_acc[db][4 * g4] * inv, o_acc[db][4 * g4 + 1] * inv);
+                w[1] = Elem<T>::pack2(o_acc[db][4 * g4 + 2] * inv, o_acc[db][4 * g4 + 3] * inv);
+                *(u32x2 *)(obuf + r * O_ROW_BYTES + (db * 32 + 8 * g4 + 4 * hh) * 2) = w;
+            }
+    }
+    __syncthreads();
+    if (wave_active) {
+        const char *obuf = smem + wave * (32 * O_ROW_BYTES);
+#pragma unroll
+        for (int i = 0; i < (32 * CH_PER_ROW) / 64; ++i) {
+            const int c = lane + i * 64;
+            const int row = c / CH_PER_ROW, ch = c % CH_PER_ROW;
+            if (wrow + row < sq && ch * 8 < p.d) {
+                const u32x4 val = *(const u32x4 *)(obuf + row * O_ROW_BYTES + ch * 16);
+                *(u32x4 *)(op + (int64_t)(wrow + row) * p.o_row_stride + ch * 8) = val;
+            }
+        }
+    }
+}
+
+template <int D, int NWAVES>
+constexpr int smem_bytes() {
+    constexpr int kv = 4 * BLOCK_N * D * 2;
+    constexpr int o = NWAVES * 32 * (D * 2 + 16);
+    return kv > o ? kv : o;
+}
+
+}  // namespace fa

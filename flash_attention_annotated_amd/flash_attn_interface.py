@@ -1,0 +1,158 @@
+"""Public Python API of the forward hot path — same names, arguments, defaults and return
+conventions as the reference's `flash_attn/flash_attn_interface.py`:
+
+    flash_attn_func                     reference :1145-1219
+    flash_attn_varlen_func              reference :1380-1471
+    flash_attn_qkvpacked_func           reference :1008-1062
+    flash_attn_kvpacked_func            reference :1065-1142
+    flash_attn_varlen_qkvpacked_func    reference :1222-1287
+    flash_attn_varlen_kvpacked_func     reference :1290-1377
+
+Host glue only (reference FlashAttnFunc.forward :817-867 / FlashAttnVarlenFunc.forward :903-968):
+default scale d**-0.5, head dim padded to a multiple of 8 and un-padded on return,
+`return_attn_probs` returning (out, softmax_lse, S_dmask).  The compute goes through the
+`flash_attn_2_cuda`-shaped module (this package's flash_attn_2_cuda.py) to the HIP kernel.
+"""
+from typing import Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+from . import flash_attn_2_cuda as flash_attn_gpu
+
+
+def maybe_contiguous(x):
+    return x.contiguous() if x is not None and x.stride(-1) != 1 else x
+
+
+def _pad_head_dim(*tensors):
+    d = tensors[0].shape[-1]
+    if d % 8 == 0:
+        return tensors
+    pad = 8 - d % 8
+    return tuple(F.pad(t, [0, pad]) for t in tensors)
+
+
+def _flash_attn_forward(q, k, v, dropout_p, softmax_scale, causal, window_size_left, window_size_right,
+                        softcap, alibi_slopes, return_softmax
+                        ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """reference :76-106"""
+    q, k, v = [maybe_contiguous(x) for x in (q, k, v)]
+    out, softmax_lse, S_dmask, rng_state = flash_attn_gpu.fwd(
+        q, k, v, None, alibi_slopes, dropout_p, softmax_scale, causal,
+        window_size_left, window_size_right, softcap, return_softmax, None)
+    return out, softmax_lse, S_dmask, rng_state
+
+
+def _flash_attn_varlen_forward(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, dropout_p,
+                               softmax_scale, causal, window_size_left=-1, window_size_right=-1, softcap=0.0,
+                               alibi_slopes=None, return_softmax=False, block_table=None, leftpad_k=None,
+                               seqused_k=None, zero_tensors=False
+                               ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """reference :145-193"""
+    q, k, v = [maybe_contiguous(x) for x in (q, k, v)]
+    out, softmax_lse, S_dmask, rng_state = flash_attn_gpu.varlen_fwd(
+        q, k, v, None, cu_seqlens_q, cu_seqlens_k, seqused_k, leftpad_k, block_table, alibi_slopes,
+        max_seqlen_q, max_seqlen_k, dropout_p, softmax_scale, zero_tensors, causal,
+        window_size_left, window_size_right, softcap, return_softmax, None)
+    return out, softmax_lse, S_dmask, rng_state
+
+
+class FlashAttnFunc(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, dropout_p, softmax_scale, causal, window_size, softcap, alibi_slopes,
+                deterministic, return_softmax, is_grad_enabled):
+        if softmax_scale is None:
+            softmax_scale = q.shape[-1] ** (-0.5)
+        head_size_og = q.size(-1)
+        qp, kp, vp = _pad_head_dim(q, k, v)
+        out_padded, softmax_lse, S_dmask, rng_state = _flash_attn_forward(
+            qp, kp, vp, dropout_p, softmax_scale, causal=causal, window_size_left=window_size[0],
+            window_size_right=window_size[1], softcap=softcap, alibi_slopes=alibi_slopes,
+            return_softmax=return_softmax and dropout_p > 0)
+        out = out_padded[..., :head_size_og]
+        return out if not return_softmax else (out, softmax_lse, S_dmask)
+
+    @staticmethod
+    def backward(ctx, dout, *args):
+        flash_attn_gpu.bwd()  # raises: forward-only back-end
+
+
+class FlashAttnVarlenFunc(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, dropout_p, softmax_scale,
+                causal, window_size, softcap, alibi_slopes, deterministic, return_softmax, block_table,
+                is_grad_enabled):
+        if softmax_scale is None:
+            softmax_scale = q.shape[-1] ** (-0.5)
+        head_size_og = q.size(-1)
+        qp, kp, vp = _pad_head_dim(q, k, v)
+        out_padded, softmax_lse, S_dmask, rng_state = _flash_attn_varlen_forward(
+            qp, kp, vp, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, dropout_p, softmax_scale,
+            causal=causal, window_size_left=window_size[0], window_size_right=window_size[1], softcap=softcap,
+            alibi_slopes=alibi_slopes, return_softmax=return_softmax and dropout_p > 0, block_table=block_table)
+        out = out_padded[..., :head_size_og]
+        return out if not return_softmax else (out, softmax_lse, S_dmask)
+
+    @staticmethod
+    def backward(ctx, dout, *args):
+        flash_attn_gpu.varlen_bwd()  # raises: forward-only back-end
+
+
+def flash_attn_func(q, k, v, dropout_p=0.0, softmax_scale=None, causal=False, window_size=(-1, -1),
+                    softcap=0.0, alibi_slopes=None, deterministic=False, return_attn_probs=False):
+    """q: (batch, seqlen_q, nheads, headdim); k, v: (batch, seqlen_k, nheads_k, headdim).
+
+    MQA/GQA: nheads % nheads_k == 0, query head i reads kv head i // (nheads / nheads_k).
+    causal masks are aligned to the BOTTOM-RIGHT corner when seqlen_q != seqlen_k; a query row with
+    no visible key produces a zero output row.  window_size=(left, right): query i sees keys in
+    [i + seqlen_k - seqlen_q - left, i + seqlen_k - seqlen_q + right].
+    Returns out (batch, seqlen_q, nheads, headdim), or (out, softmax_lse (batch, nheads, seqlen_q),
+    S_dmask) when return_attn_probs.
+    """
+    return FlashAttnFunc.apply(q, k, v, dropout_p, softmax_scale, causal, window_size, softcap, alibi_slopes,
+                               deterministic, return_attn_probs, torch.is_grad_enabled())
+
+
+def flash_attn_varlen_func(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, dropout_p=0.0,
+                           softmax_scale=None, causal=False, window_size=(-1, -1), softcap=0.0,
+                           alibi_slopes=None, deterministic=False, return_attn_probs=False, block_table=None):
+    """q: (total_q, nheads, headdim); k, v: (total_k, nheads_k, headdim); cu_seqlens_*: (batch+1,) int32.
+
+    Returns out (total_q, nheads, headdim), or (out, softmax_lse (nheads, total_q), S_dmask).
+    """
+    return FlashAttnVarlenFunc.apply(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, dropout_p,
+                                     softmax_scale, causal, window_size, softcap, alibi_slopes, deterministic,
+                                     return_attn_probs, block_table, torch.is_grad_enabled())
+
+
+def flash_attn_qkvpacked_func(qkv, dropout_p=0.0, softmax_scale=None, causal=False, window_size=(-1, -1),
+                              softcap=0.0, alibi_slopes=None, deterministic=False, return_attn_probs=False):
+    """qkv: (batch, seqlen, 3, nheads, headdim).  The three views are read in place (row stride 3*h*d)."""
+    return flash_attn_func(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], dropout_p, softmax_scale, causal,
+                           window_size, softcap, alibi_slopes, deterministic, return_attn_probs)
+
+
+def flash_attn_kvpacked_func(q, kv, dropout_p=0.0, softmax_scale=None, causal=False, window_size=(-1, -1),
+                             softcap=0.0, alibi_slopes=None, deterministic=False, return_attn_probs=False):
+    """q: (batch, seqlen_q, nheads, headdim); kv: (batch, seqlen_k, 2, nheads_k, headdim)."""
+    return flash_attn_func(q, kv[:, :, 0], kv[:, :, 1], dropout_p, softmax_scale, causal, window_size, softcap,
+                           alibi_slopes, deterministic, return_attn_probs)
+
+
+def flash_attn_varlen_qkvpacked_func(qkv, cu_seqlens, max_seqlen, dropout_p=0.0, softmax_scale=None, causal=False,
+                                     window_size=(-1, -1), softcap=0.0, alibi_slopes=None, deterministic=False,
+                                     return_attn_probs=False):
+    """qkv: (total, 3, nheads, headdim)."""
+    return flash_attn_varlen_func(qkv[:, 0], qkv[:, 1], qkv[:, 2], cu_seqlens, cu_seqlens, max_seqlen, max_seqlen,
+                                  dropout_p, softmax_scale, causal, window_size, softcap, alibi_slopes,
+                                  deterministic, return_attn_probs)
+
+
+def flash_attn_varlen_kvpacked_func(q, kv, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, dropout_p=0.0,
+                                    softmax_scale=None, causal=False, window_size=(-1, -1), softcap=0.0,
+                                    alibi_slopes=None, deterministic=False, return_attn_probs=False):
+    """q: (total_q, nheads, headdim); kv: (total_k, 2, nheads_k, headdim)."""
+    return flash_attn_varlen_func(q, kv[:, 0], kv[:, 1], cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k,
+                                  dropout_p, softmax_scale, causal, window_size, softcap, alibi_slopes,
+                                  deterministic, return_attn_probs)

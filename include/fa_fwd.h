@@ -1,0 +1,148 @@
+/*
+ * fa_fwd.h — C-ABI of the MI355X (gfx950) FlashAttention forward.
+ *
+ * This is the drop-in boundary of the hot path.  Plain C, raw
+ * device pointers, element strides, int status codes; no torch types.  It is
+ * what a binding for the reference's forward entry points would call:
+ *
+ *   reference interface replaced                                  entry point here
+ *   ------------------------------------------------------------  -----------------
+ *   mha_fwd          csrc/flash_attn/flash_api.cpp:350-512        fa_fwd (dense)
+ *   mha_varlen_fwd   csrc/flash_attn/flash_api.cpp:514-755        fa_fwd (cu_seqlens_* set)
+ *   mha_fwd (FA3)    hopper/flash_api.cpp:672-1198                fa_fwd (+ seqused_*, descale)
+ *   set_params_fprop csrc/flash_attn/flash_api.cpp:26-159         fa_fwd_params (field for field)
+ *   Flash_fwd_params csrc/flash_attn/src/flash.h:48-143,
+ *                    hopper/flash.h:37-168                        fa_fwd_params
+ *   flash_attention_forward(FlashAttentionParams&, cudaStream_t)
+ *                    standalone/include/flash_api.h:222-225       fa_fwd(const fa_fwd_params*, void*)
+ *   error codes      standalone/src/flash_api.cu:403-426          FA_ERR_* / fa_strerror
+ *
+ * Conventions (same as the reference's params struct):
+ *   - strides are in ELEMENTS, not bytes (csrc/flash_attn/flash_api.cpp:64-73);
+ *     the last (head_dim) stride of q/k/v/o must be 1;
+ *   - dense layout  q:(b, seqlen_q, h, d)  k,v:(b, seqlen_k, h_k, d)  o like q,
+ *     softmax_lse:(b, h, seqlen_q) fp32;
+ *   - varlen layout q:(total_q, h, d) k,v:(total_k, h_k, d), cu_seqlens_{q,k}
+ *     int32 (b+1) device arrays, softmax_lse:(h, total_q) fp32
+ *     (csrc/flash_attn/flash_api.cpp:652); *_batch_stride is ignored;
+ *   - the callee never allocates, never synchronises and launches on `stream`;
+ *   - outputs are written in place; inputs are borrowed.
+ */
+#ifndef FA_FWD_H_
+#define FA_FWD_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FA_ABI_VERSION 1
+
+/* element types of q/k/v (o has the same type; fp8 inputs produce bf16 o) */
+enum fa_dtype {
+    FA_DTYPE_FP16 = 0,
+    FA_DTYPE_BF16 = 1,
+    FA_DTYPE_FP8_E4M3 = 2 /* OCP e4m3fn; hopper/flash_api.cpp:714-722 */
+};
+
+/* status codes: 0 ok, negative = rejected before launch, nothing was written */
+enum fa_status {
+    FA_OK = 0,
+    FA_ERR_NULL_POINTER = -1,      /* a required pointer is NULL */
+    FA_ERR_BAD_DTYPE = -2,         /* "FlashAttention only support fp16 and bf16 data type" */
+    FA_ERR_BAD_HEAD_DIM = -3,      /* d > 256 or d % 8 != 0 */
+    FA_ERR_BAD_HEADS = -4,         /* h % h_k != 0 */
+    FA_ERR_BAD_SHAPE = -5,         /* b <= 0, negative lengths, ... */
+    FA_ERR_BAD_STRIDE = -6,        /* misaligned rows: strides must keep 16-byte row alignment */
+    FA_ERR_UNSUPPORTED = -7,       /* feature accepted by the ABI but not built (alibi, dropout, ...) */
+    FA_ERR_LAUNCH = -8,            /* hipLaunchKernel failed */
+    FA_ERR_BAD_ABI = -9,           /* params->abi_version / struct size mismatch */
+    FA_ERR_NO_DEVICE = -10         /* not a gfx950 device */
+};
+
+/*
+ * Mirrors Flash_fwd_params (csrc/flash_attn/src/flash.h:48-143) restricted to
+ * the forward hot path, plus the FA3 additions used by BASELINE config 5
+ * (hopper/flash.h:37-168: seqused_q/k, q/k/v descale).
+ */
+typedef struct fa_fwd_params {
+    uint32_t abi_version; /* FA_ABI_VERSION */
+    uint32_t struct_size; /* sizeof(fa_fwd_params) */
+
+    /* tensors (device pointers) */
+    const void *q;
+    const void *k;
+    const void *v;
+    void *o;
+    float *softmax_lse;
+
+    /* element strides; head_dim stride is 1 */
+    int64_t q_batch_stride, q_row_stride, q_head_stride;
+    int64_t k_batch_stride, k_row_stride, k_head_stride;
+    int64_t v_batch_stride, v_row_stride, v_head_stride;
+    int64_t o_batch_stride, o_row_stride, o_head_stride;
+
+    /* sizes */
+    int32_t b;        /* batch (varlen: number of sequences) */
+    int32_t seqlen_q; /* dense: seqlen_q; varlen: max_seqlen_q */
+    int32_t seqlen_k; /* dense: seqlen_k; varlen: max_seqlen_k */
+    int32_t h;        /* query heads */
+    int32_t h_k;      /* key/value heads; h % h_k == 0; q head i reads kv head i / (h/h_k) */
+    int32_t d;        /* head dim, multiple of 8, <= 256 */
+    int32_t total_q;  /* varlen: rows of q (lse row length); dense: ignored */
+    int32_t dtype;    /* enum fa_dtype */
+
+    /* varlen bookkeeping (NULL => dense); BlockInfo csrc/flash_attn/src/block_info.h:12-45 */
+    const int32_t *cu_seqlens_q; /* (b+1) */
+    const int32_t *cu_seqlens_k; /* (b+1) */
+    const int32_t *seqused_q;    /* (b) optional: rows actually used (FA3 hopper/seqlen.h:32-93) */
+    const int32_t *seqused_k;    /* (b) optional: keys actually used */
+
+    /* softmax */
+    float softmax_scale; /* scores = q.k * softmax_scale */
+    float softcap;       /* >0: scores = softcap * tanh(scores / softcap) */
+
+    /* masking: bottom-right aligned (flash_attn/flash_attn_interface.py:1164-1174) */
+    int32_t is_causal;         /* != 0 => window_size_right = 0 */
+    int32_t window_size_left;  /* <0: unbounded */
+    int32_t window_size_right; /* <0: unbounded */
+
+    /* fp8 only: per-(batch, kv head) fp32 descales (hopper/flash_api.cpp:1115-1146); NULL = 1.0 */
+    const float *q_descale, *k_descale, *v_descale;
+    int64_t q_descale_batch_stride, q_descale_head_stride;
+    int64_t k_descale_batch_stride, k_descale_head_stride;
+    int64_t v_descale_batch_stride, v_descale_head_stride;
+
+    /* performance hint, never changes results: 0 = library default */
+    int32_t kernel_variant;
+    int32_t reserved0;
+} fa_fwd_params;
+
+/* Validate and enqueue the forward on `stream` (a hipStream_t; NULL = default
+ * stream).  Returns FA_OK or a negative fa_status; asynchronous. */
+int fa_fwd(const fa_fwd_params *params, void *stream);
+
+/* Validation only (what mha_fwd's TORCH_CHECKs do); no device access. */
+int fa_fwd_validate(const fa_fwd_params *params);
+
+/* Human-readable text for a status code (static storage). */
+const char *fa_strerror(int status);
+
+/* sizeof(fa_fwd_params) as compiled, for binding self-checks. */
+uint32_t fa_fwd_params_size(void);
+
+/* FA_ABI_VERSION as compiled. */
+uint32_t fa_abi_version(void);
+
+/* Tile geometry chosen for (d, dtype, causal): writes block_m / block_n.
+ * Role of tile_size_fwd_sm90 (hopper/tile_size.h:10-54). */
+int fa_fwd_tile_shape(int32_t d, int32_t dtype, int32_t is_causal, int32_t *block_m, int32_t *block_n);
+
+/* Test hook: overrides the default kernel variant process-wide (0 = default). */
+void fa_set_default_variant(int32_t variant);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FA_FWD_H_ */

@@ -1,0 +1,125 @@
+"""ORACLE — test infrastructure only.  Never imported by the product path.
+
+CPU/torch restatement of the reference's exact-attention oracle `attention_ref`
+(tests/test_util.py:185-274 == tests/test_flash_attn.py:217-304; FA3 flavour
+hopper/test_util.py:226-348) and its mask builder `construct_local_mask`
+(tests/test_util.py:150-182).  Only `tests/`, `__graft_entry__.smoke()` and the
+`cpu_baseline` leg of `bench.py` may import this module.
+
+Pinned: `oracle/make_golden.py` (run in the build container, where /root/reference is
+mounted) asserts this restatement equals the reference's own `attention_ref` on a sweep
+(dense / causal / sq != sk / GQA / padding masks / local windows / softcap / low-precision
+reorder) and freezes inputs+outputs into tests/golden/*.pt; `tests/test_oracle.py` replays
+those fixtures without the reference.
+"""
+import math
+
+import torch
+
+
+def local_mask(seqlen_q, seqlen_k, window_size=(-1, -1), query_padding_mask=None, key_padding_mask=None,
+               device=None):
+    """True where key j is NOT visible from query i.  Bottom-right aligned:
+    visible iff  i + sk - sq - left <= j <= min(i + sk - sq + right, sk)   (tests/test_util.py:150-182).
+    With padding masks sk / sq are the per-batch valid lengths and the result is (b,1,sq,sk)."""
+    i = torch.arange(seqlen_q, device=device, dtype=torch.long).view(-1, 1)
+    j = torch.arange(seqlen_k, device=device, dtype=torch.long).view(1, -1)
+    sk = seqlen_k if key_padding_mask is None else key_padding_mask.sum(-1).view(-1, 1, 1, 1)
+    sq = seqlen_q if query_padding_mask is None else query_padding_mask.sum(-1).view(-1, 1, 1, 1)
+    left, right = window_size
+    diag = i + sk - sq
+    if left < 0:
+        return j > diag + right
+    sk_t = torch.full_like(j, seqlen_k) if key_padding_mask is None else sk
+    return torch.logical_or(j > torch.minimum(diag + right, sk_t), j < diag - left)
+
+
+def attention_ref(q, k, v, query_padding_mask=None, key_padding_mask=None, attn_bias=None, causal=False,
+                  window_size=(-1, -1), softcap=0.0, upcast=True, reorder_ops=False, return_lse=False):
+    """Exact softmax attention.
+
+    q: (b, sq, h, d); k, v: (b, sk, h_k, d) with h % h_k == 0 (kv head = q head // (h/h_k)).
+    upcast=True  -> everything in fp32 ("out_ref" of the reference's tests);
+    upcast=False, reorder_ops=True -> same math in the input precision with k scaled instead of q
+    ("out_pt", the yardstick of the tolerance contract, tests/test_flash_attn.py:1121).
+    Returns (out (b,sq,h,d) in q.dtype, attention (b,h,sq,sk)) and, if return_lse, the fp32
+    logsumexp (b,h,sq) of the masked, scaled scores (+inf where no key is visible, the FA2
+    convention csrc/flash_attn/src/softmax.h:178-180).
+    """
+    if causal:
+        window_size = (window_size[0], 0)
+    dtype_og = q.dtype
+    if upcast:
+        q, k, v = q.float(), k.float(), v.float()
+    b, sq, h, d = q.shape
+    sk = k.shape[1]
+    g = h // k.shape[2]
+    k = k.repeat_interleave(g, dim=2)
+    v = v.repeat_interleave(g, dim=2)
+    if not reorder_ops:
+        scores = torch.einsum("bthd,bshd->bhts", q / math.sqrt(d), k)
+    else:
+        scores = torch.einsum("bthd,bshd->bhts", q, k / math.sqrt(d))
+    if softcap > 0:
+        scores = torch.tanh(scores / softcap) * softcap
+    if key_padding_mask is not None:
+        scores = scores.masked_fill(~key_padding_mask.view(b, 1, 1, sk), float("-inf"))
+    masked = None
+    if window_size[0] >= 0 or window_size[1] >= 0:
+        masked = local_mask(sq, sk, window_size, query_padding_mask, key_padding_mask, q.device)
+        scores = scores.masked_fill(masked, float("-inf"))
+    if attn_bias is not None:
+        scores = scores + attn_bias
+    lse = torch.logsumexp(scores.float(), dim=-1)
+    attention = torch.softmax(scores, dim=-1).to(v.dtype)
+    if masked is not None:  # fully masked rows: zeros instead of NaN
+        attention = attention.masked_fill(torch.all(masked, dim=-1, keepdim=True), 0.0)
+    if query_padding_mask is not None:
+        attention = attention.masked_fill(~query_padding_mask.view(b, 1, sq, 1), 0.0)
+    out = torch.einsum("bhts,bshd->bthd", attention, v)
+    if query_padding_mask is not None:
+        out = out.masked_fill(~query_padding_mask.view(b, sq, 1, 1), 0.0)
+    if key_padding_mask is not None:
+        out = out.masked_fill(~torch.any(key_padding_mask, 1).view(b, 1, 1, 1), 0.0)
+    out = out.to(dtype_og)
+    if return_lse:
+        lse = torch.where(torch.isneginf(lse), torch.full_like(lse, float("inf")), lse)
+        return out, attention.to(dtype_og), lse
+    return out, attention.to(dtype_og)
+
+
+def attention_varlen_ref(q, k, v, cu_seqlens_q, cu_seqlens_k, causal=False, window_size=(-1, -1), softcap=0.0,
+                         upcast=True, reorder_ops=False, seqused_k=None):
+    """Packed ragged batch: q (total_q,h,d), k/v (total_k,h_k,d).  Loops over sequences with
+    attention_ref; returns out (total_q,h,d) and lse (h,total_q) — the layout of
+    mha_varlen_fwd (csrc/flash_attn/flash_api.cpp:652)."""
+    cq = cu_seqlens_q.tolist()
+    ck = cu_seqlens_k.tolist()
+    out = torch.zeros_like(q)
+    lse = torch.full((q.shape[1], q.shape[0]), float("inf"), dtype=torch.float32, device=q.device)
+    for i in range(len(cq) - 1):
+        q0, q1, k0, k1 = cq[i], cq[i + 1], ck[i], ck[i + 1]
+        if seqused_k is not None:
+            k1 = k0 + int(seqused_k[i])
+        if q1 == q0:
+            continue
+        if k1 == k0:
+            continue  # zero keys: out = 0, lse = +inf
+        o, _, l = attention_ref(q[q0:q1][None], k[k0:k1][None], v[k0:k1][None], causal=causal,
+                                window_size=window_size, softcap=softcap, upcast=upcast,
+                                reorder_ops=reorder_ops, return_lse=True)
+        out[q0:q1] = o[0]
+        lse[:, q0:q1] = l[0]
+    return out, lse
+
+
+def sdpa_cpu(q, k, v, causal=False):
+    """PyTorch-eager fused CPU attention on (b,s,h,d) tensors — the CPU baseline BASELINE.json names
+    ("PyTorch-eager SDPA timed on the same box's host CPUs").  Top-left causal == bottom-right when sq == sk."""
+    import torch.nn.functional as F
+    g = q.shape[2] // k.shape[2]
+    if g > 1:
+        k = k.repeat_interleave(g, dim=2)
+        v = v.repeat_interleave(g, dim=2)
+    o = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), is_causal=causal)
+    return o.transpose(1, 2)

@@ -1,0 +1,77 @@
+"""ORACLE — test infrastructure only.  Seeded input recipes shared by oracle/make_golden.py
+(which freezes the reference's outputs for them) and tests/ (which replay them).
+
+Shapes follow the reference's own test matrix in miniature (tests/test_flash_attn.py:878-919:
+odd (sq, sk) pairs such as (113, 203), mha/mqa/gqa, causal x local, random padding masks with
+lengths in [max-20, max] :58-71; the (2,5)/(5,2) masks of the flash_attn_func docstring
+flash_attn/flash_attn_interface.py:1164-1174) plus BASELINE config 1 (b2 h4 d64 s512 fp32).
+"""
+import torch
+
+_DT = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}
+
+
+def _case(dtype, b, sq, sk, h, hk, d, causal=False, window=(-1, -1), softcap=0.0, padding="none", seed=0,
+          q_scale=1.0, store_row_stride=1):
+    if store_row_stride == 1:  # keep fixtures small: store every n-th query row of the big cases
+        store_row_stride = max(1, (b * sq * h * d) // 12288)
+    return dict(dtype=dtype, b=b, sq=sq, sk=sk, h=h, hk=hk, d=d, causal=causal, window=tuple(window),
+                softcap=softcap, padding=padding, seed=seed, q_scale=q_scale, store_row_stride=store_row_stride)
+
+
+CASES = {
+    # BASELINE.json configs[0]: the reference's own CPU-runnable case
+    "c1_fp32_b2_s512_h4_d64": _case("fp32", 2, 512, 512, 4, 4, 64, store_row_stride=16),
+    "c1_fp32_b2_s512_h4_d64_causal": _case("fp32", 2, 512, 512, 4, 4, 64, causal=True, store_row_stride=16),
+    # docstring mask diagrams (bottom-right alignment, fully masked rows -> 0)
+    "doc_causal_sq2_sk5": _case("bf16", 1, 2, 5, 2, 2, 32, causal=True, seed=1),
+    "doc_causal_sq5_sk2": _case("bf16", 1, 5, 2, 2, 2, 32, causal=True, seed=2),
+    # dense, mha / gqa / mqa, odd lengths, both 16-bit types
+    "bf16_dense_128_d64": _case("bf16", 2, 128, 128, 4, 4, 64, seed=3),
+    "fp16_dense_128_d64": _case("fp16", 2, 128, 128, 4, 4, 64, seed=4),
+    "bf16_113_203_gqa_d64": _case("bf16", 2, 113, 203, 6, 2, 64, seed=5),
+    "bf16_113_203_gqa_d64_causal": _case("bf16", 2, 113, 203, 6, 2, 64, causal=True, seed=6),
+    "bf16_203_113_mqa_d128_causal": _case("bf16", 1, 203, 113, 4, 1, 128, causal=True, seed=7),
+    "fp16_256_384_d128": _case("fp16", 1, 256, 384, 2, 2, 128, seed=8),
+    "bf16_d40": _case("bf16", 1, 108, 256, 2, 2, 40, causal=True, seed=9),
+    "bf16_d96": _case("bf16", 1, 99, 130, 2, 1, 96, seed=10),
+    "bf16_d256_causal": _case("bf16", 1, 130, 150, 2, 1, 256, causal=True, seed=11),
+    # sliding windows
+    "bf16_local_64_0": _case("bf16", 1, 200, 200, 2, 2, 64, window=(64, 0), seed=12),
+    "bf16_local_16_16_sq_ne_sk": _case("bf16", 1, 113, 203, 2, 2, 64, window=(16, 16), seed=13),
+    "bf16_local_0_32": _case("bf16", 1, 150, 120, 2, 1, 64, window=(0, 32), seed=14),
+    # softcap (scores pushed into the tanh knee like hopper/test_flash_attn.py:139-140)
+    "bf16_softcap30": _case("bf16", 1, 128, 160, 2, 2, 64, softcap=30.0, q_scale=7.5, seed=15),
+    # ragged batches (key / query padding)
+    "bf16_padded_causal": _case("bf16", 3, 128, 217, 4, 2, 64, causal=True, padding="random", seed=16),
+    "fp16_padded": _case("fp16", 3, 97, 97, 2, 2, 128, padding="random", seed=17),
+}
+
+
+def make_inputs(c):
+    """q, k, v in that order from torch.manual_seed(seed) (CPU generator: deterministic across hosts)."""
+    g = torch.Generator().manual_seed(1000 + c["seed"])
+    dt = _DT[c["dtype"]]
+    q = torch.randn(c["b"], c["sq"], c["h"], c["d"], generator=g, dtype=torch.float32)
+    k = torch.randn(c["b"], c["sk"], c["hk"], c["d"], generator=g, dtype=torch.float32)
+    v = torch.randn(c["b"], c["sk"], c["hk"], c["d"], generator=g, dtype=torch.float32)
+    q = q * c["q_scale"]
+    return q.to(dt), k.to(dt), v.to(dt)
+
+
+def padding_masks(c):
+    """(query_padding_mask, key_padding_mask) bool (b, s) or (None, None).  Lengths in [max-20, max]."""
+    if c["padding"] == "none":
+        return None, None
+    g = torch.Generator().manual_seed(2000 + c["seed"])
+
+    def one(smax):
+        lens = torch.randint(max(1, smax - 20), smax + 1, (c["b"], 1), generator=g)
+        return torch.arange(smax).view(1, -1) < lens
+    return one(c["sq"]), one(c["sk"])
+
+
+def checksum(t):
+    t = t.double()
+    w = torch.arange(1, t.numel() + 1, dtype=torch.float64).reshape(t.shape) % 7 + 1
+    return float((t * w).sum().item())

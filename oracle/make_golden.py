@@ -1,0 +1,117 @@
+"""ORACLE tooling — run ONLY in the build container (needs /root/reference, read-only).
+
+1. Imports the reference's own pure-torch oracle `attention_ref`
+   (/root/reference/tests/test_util.py:185-274 and /root/reference/hopper/test_util.py:226-348)
+   and asserts that this repo's restatement (oracle/attention_ref.py) and the C fp64 restatement
+   (oracle/attention_ref_c.c) reproduce it on a sweep of cases.
+2. Freezes the reference's outputs into tests/golden/attention_ref_golden.pt so the GPU box
+   (which never sees /root/reference) can replay them.  Inputs are stored as a seed recipe plus a
+   checksum; outputs are stored in full.  A fixture is data only: no reference source text.
+
+Usage:  python oracle/make_golden.py
+"""
+import ctypes
+import importlib.util
+import os
+import sys
+import types
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+
+from oracle import attention_ref as mine  # noqa: E402
+from oracle.cases import CASES, make_inputs, padding_masks, checksum  # noqa: E402
+
+
+def import_reference():
+    """tests/test_util.py pulls in the `flash_attn` package, whose __init__ imports the compiled
+    extension; an empty stand-in module object lets the pure-Python parts import."""
+    sys.modules.setdefault("flash_attn_2_cuda", types.ModuleType("flash_attn_2_cuda"))
+    sys.path.insert(0, REF)
+    spec = importlib.util.spec_from_file_location("ref_test_util_fa2", os.path.join(REF, "tests/test_util.py"))
+    fa2 = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fa2)
+    sys.path.insert(0, os.path.join(REF, "hopper"))
+    spec = importlib.util.spec_from_file_location("ref_test_util_fa3", os.path.join(REF, "hopper/test_util.py"))
+    fa3 = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fa3)
+    return fa2, fa3
+
+
+def c_oracle():
+    path = os.path.join(ROOT, "oracle/_ref/liboracle_attn.so")
+    lib = ctypes.CDLL(path)
+    f = lib.fa_oracle_attention_f32
+    f.restype = ctypes.c_int
+    f.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] * 6 + [ctypes.c_float] + [ctypes.c_int] * 3 + [ctypes.c_float]
+
+    def run(q, k, v, scale, causal, window, softcap):
+        q, k, v = (t.float().contiguous() for t in (q, k, v))
+        b, sq, h, d = q.shape
+        sk, hk = k.shape[1], k.shape[2]
+        out = torch.empty_like(q)
+        lse = torch.empty(b, h, sq, dtype=torch.float32)
+        st = f(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(), b, sq, sk, h, hk, d,
+               scale, int(causal), window[0], window[1], softcap)
+        assert st == 0
+        return out, lse
+    return run
+
+
+def main():
+    fa2, fa3 = import_reference()
+    crun = c_oracle()
+    golden = {}
+    worst = 0.0
+    for name, c in CASES.items():
+        q, k, v = make_inputs(c)
+        qm, km = padding_masks(c)
+        kw = dict(causal=c["causal"], window_size=c["window"], softcap=c["softcap"])
+        # the reference, three ways: fp32 ("out_ref"), low-precision reordered ("out_pt"), FA3 flavour
+        ref_out, ref_attn = fa2.attention_ref(q, k, v, qm, km, **kw)
+        ref_pt, _ = fa2.attention_ref(q, k, v, qm, km, **kw, upcast=False, reorder_ops=True)
+        ref3_out, _ = fa3.attention_ref(q, k, v, qm, km, **kw)
+        ref_out32, _ = fa2.attention_ref(q.float(), k.float(), v.float(), qm, km, **kw)
+        # this repo's restatement
+        my_out, my_attn, my_lse = mine.attention_ref(q, k, v, qm, km, **kw, return_lse=True)
+        my_pt, _ = mine.attention_ref(q, k, v, qm, km, **kw, upcast=False, reorder_ops=True)
+        my_out32, _ = mine.attention_ref(q.float(), k.float(), v.float(), qm, km, **kw)
+        e1 = (my_out32 - ref_out32).abs().max().item()
+        e2 = (my_pt.float() - ref_pt.float()).abs().max().item()
+        e3 = (my_out.float() - ref3_out.float()).abs().max().item()
+        e4 = (my_attn.float() - ref_attn.float()).abs().max().item()
+        assert e1 <= 1e-6, (name, "fp32 restatement vs reference", e1)
+        assert e2 == 0.0, (name, "low-precision reordered restatement vs reference", e2)
+        assert torch.equal(my_out, ref_out), (name, "cast output differs")
+        assert e3 <= (1e-6 if q.dtype == torch.float32 else 8e-3), (name, "vs FA3-flavour oracle", e3)
+        assert e4 <= 1e-6 if q.dtype == torch.float32 else e4 <= 4e-3, (name, "attention probs", e4)
+        worst = max(worst, e1)
+        # C fp64 restatement (dense cases only: no padding masks)
+        if qm is None and km is None:
+            scale = q.shape[-1] ** -0.5
+            c_out, c_lse = crun(q, k, v, scale, c["causal"], c["window"], c["softcap"])
+            e5 = (c_out - ref_out32).abs().max().item()
+            assert e5 <= 1e-5, (name, "C oracle (fp64) vs reference (fp32)", e5)
+            fin = torch.isfinite(my_lse)
+            assert torch.equal(fin, torch.isfinite(c_lse)), (name, "lse inf pattern")
+            e6 = (c_lse[fin] - my_lse[fin]).abs().max().item() if fin.any() else 0.0
+            assert e6 <= 2e-5, (name, "lse torch vs C", e6)
+        stride = c.get("store_row_stride", 1)
+        golden[name] = {
+            "case": {k2: (list(v2) if isinstance(v2, tuple) else v2) for k2, v2 in c.items()},
+            "input_checksum": torch.tensor([checksum(q), checksum(k), checksum(v)], dtype=torch.float64),
+            "out_ref_fp32": ref_out32[:, ::stride].contiguous(),   # reference, fp32 math on upcast inputs
+            "out_pt": ref_pt[:, ::stride].contiguous(),            # reference in low precision, reordered
+            "lse": my_lse[:, :, ::stride].contiguous(),            # restatement (checked against the C oracle)
+        }
+        print(f"{name:34s} fp32 err {e1:.2e}  pt err {e2:.1e}  fa3 err {e3:.2e}")
+    out_path = os.path.join(ROOT, "tests/golden/attention_ref_golden.pt")
+    torch.save(golden, out_path)
+    print(f"wrote {out_path} ({os.path.getsize(out_path) / 1e6:.2f} MB), worst fp32 deviation {worst:.2e}")
+
+
+if __name__ == "__main__":
+    main()

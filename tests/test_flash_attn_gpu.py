@@ -1,0 +1,313 @@
+"""GPU parity tests of the HIP forward against the oracle, through the public API and the C-ABI.
+
+Ports the reference's tolerance contract as inequalities:
+  FA2  |out - out_ref|max <= 2 * |out_pt - out_ref|max (+1e-5 in the causal tests)
+       tests/test_flash_attn.py:1121,1440,1556
+  FA3  <= rtol * |out_pt - out_ref|max + fwd_atol, fwd_atol = 2*|(out_ref + 0.3 - 0.3) - out_ref|max
+       hopper/test_flash_attn.py:193-194,223
+The bound used here is the FA2 one plus the FA3 atol (floating point; tolerance stated per test).
+"""
+import math
+
+import pytest
+import torch
+
+from oracle import attention_ref as oracle
+from oracle.cases import CASES, checksum, make_inputs, padding_masks
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _api():
+    import flash_attention_annotated_amd as fa
+    return fa
+
+
+def _bound(out_ref, out_pt):
+    fwd_atol = 2 * (out_ref + 0.3 - 0.3 - out_ref).abs().max().item()
+    return 2 * (out_pt.float() - out_ref.float()).abs().max().item() + fwd_atol + 1e-5
+
+
+def _check(out, out_ref, out_pt, what=""):
+    err = (out.float().cpu() - out_ref.float()).abs().max().item()
+    bound = _bound(out_ref.float(), out_pt)
+    assert math.isfinite(err), f"{what}: non-finite output"
+    assert err <= bound, f"{what}: max err {err:.3e} > bound {bound:.3e}"
+    return err, bound
+
+
+def _dense_ref(q, k, v, **kw):
+    out_ref, _, lse = oracle.attention_ref(q, k, v, **kw, return_lse=True)
+    out_pt, _ = oracle.attention_ref(q, k, v, **kw, upcast=False, reorder_ops=True)
+    return out_ref, out_pt, lse
+
+
+def _check_lse(lse, lse_ref, tol=2e-3):
+    lse = lse.float().cpu()
+    fin = torch.isfinite(lse_ref)
+    assert torch.equal(torch.isfinite(lse), fin), "lse inf pattern differs"
+    assert torch.equal(lse[~fin], lse_ref[~fin]), "lse +inf rows differ"
+    if fin.any():
+        err = (lse[fin] - lse_ref[fin]).abs().max().item()
+        assert err <= tol, f"lse err {err:.3e}"
+
+
+@pytest.mark.parametrize("name", [n for n, c in CASES.items() if c["dtype"] != "fp32"])
+def test_golden_cases(name, golden):
+    """Every 16-bit golden case: HIP output vs the reference's frozen out_ref / out_pt."""
+    fa = _api()
+    c = CASES[name]
+    g = golden[name]
+    q, k, v = make_inputs(c)
+    assert abs(checksum(q) - g["input_checksum"][0].item()) < 1e-6
+    qm, km = padding_masks(c)
+    stride = c["store_row_stride"]
+    kw = dict(causal=c["causal"], window_size=c["window"], softcap=c["softcap"])
+    if qm is None:
+        out, lse, _ = fa.flash_attn_func(q.to(DEV), k.to(DEV), v.to(DEV), **kw, return_attn_probs=True)
+        out_ref_full, out_pt_full, lse_ref = _dense_ref(q, k, v, **kw)
+    else:
+        from flash_attention_annotated_amd.bert_padding import pad_input, unpad_input
+        qu, iq, cuq, mq, _ = unpad_input(q, qm)
+        ku, ik, cuk, mk, _ = unpad_input(k, km)
+        vu = unpad_input(v, km)[0]
+        out_u = fa.flash_attn_varlen_func(qu.to(DEV), ku.to(DEV), vu.to(DEV), cuq.to(DEV), cuk.to(DEV), mq, mk, **kw)
+        out = pad_input(out_u.cpu(), iq, c["b"], c["sq"])
+        lse = None
+    err, bound = _check(out[:, ::stride], g["out_ref_fp32"], g["out_pt"], name)
+    if lse is not None:
+        _check_lse(lse[:, :, ::stride], g["lse"])
+
+
+SHAPES = [(1, 1), (1, 147), (64, 128), (113, 203), (128, 217), (203, 113), (256, 256), (257, 1), (384, 256),
+          (512, 512), (1023, 1024), (1024, 1023), (2048, 2048)]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("d", [64, 128])
+@pytest.mark.parametrize("sq,sk", SHAPES)
+@pytest.mark.parametrize("mha_type", ["mha", "gqa", "mqa"])
+def test_dense_output(sq, sk, d, causal, dtype, mha_type):
+    """Shape matrix in the style of tests/test_flash_attn.py:878-919 (batch 4 -> 2, heads 6)."""
+    if mha_type != "mha" and (sq, sk) not in [(113, 203), (512, 512), (1023, 1024)]:
+        pytest.skip("gqa/mqa on a subset of shapes")
+    fa = _api()
+    torch.manual_seed(0)
+    b, h = 2, 6
+    hk = {"mha": 6, "gqa": 2, "mqa": 1}[mha_type]
+    q = torch.randn(b, sq, h, d, dtype=dtype)
+    k = torch.randn(b, sk, hk, d, dtype=dtype)
+    v = torch.randn(b, sk, hk, d, dtype=dtype)
+    out, lse, _ = fa.flash_attn_func(q.to(DEV), k.to(DEV), v.to(DEV), causal=causal, return_attn_probs=True)
+    out_ref, out_pt, lse_ref = _dense_ref(q, k, v, causal=causal)
+    _check(out, out_ref, out_pt, f"{sq}x{sk} d{d} causal={causal} {mha_type}")
+    _check_lse(lse, lse_ref)
+
+
+@pytest.mark.parametrize("d", [32, 40, 59, 96, 111, 160, 192, 224, 256])
+@pytest.mark.parametrize("causal", [False, True])
+def test_head_dims(d, causal):
+    """Head dims of tests/test_flash_attn.py:878 that are not a tile width: padded to x8 by the Python
+    layer (flash_attn_interface.py:839-843) and to the tile width inside the kernel."""
+    fa = _api()
+    torch.manual_seed(1)
+    q = torch.randn(2, 217, 4, d, dtype=torch.bfloat16)
+    k = torch.randn(2, 330, 2, d, dtype=torch.bfloat16)
+    v = torch.randn(2, 330, 2, d, dtype=torch.bfloat16)
+    out = fa.flash_attn_func(q.to(DEV), k.to(DEV), v.to(DEV), causal=causal)
+    assert out.shape == q.shape
+    out_ref, out_pt, _ = _dense_ref(q, k, v, causal=causal)
+    _check(out, out_ref, out_pt, f"d={d}")
+
+
+@pytest.mark.parametrize("window", [(64, 0), (16, 16), (0, 32), (300, -1), (-1, 17), (0, 0)])
+@pytest.mark.parametrize("sq,sk", [(113, 203), (512, 512), (700, 333)])
+def test_local_window(sq, sk, window):
+    fa = _api()
+    torch.manual_seed(2)
+    q = torch.randn(2, sq, 4, 64, dtype=torch.bfloat16)
+    k = torch.randn(2, sk, 2, 64, dtype=torch.bfloat16)
+    v = torch.randn(2, sk, 2, 64, dtype=torch.bfloat16)
+    out, lse, _ = fa.flash_attn_func(q.to(DEV), k.to(DEV), v.to(DEV), window_size=window, return_attn_probs=True)
+    out_ref, out_pt, lse_ref = _dense_ref(q, k, v, window_size=window)
+    _check(out, out_ref, out_pt, f"window={window}")
+    _check_lse(lse, lse_ref)
+
+
+@pytest.mark.parametrize("causal", [False, True])
+def test_softcap(causal):
+    fa = _api()
+    torch.manual_seed(3)
+    softcap = 30.0
+    q = torch.randn(2, 300, 4, 128, dtype=torch.bfloat16) * (softcap / 4)
+    k = torch.randn(2, 421, 4, 128, dtype=torch.bfloat16)
+    v = torch.randn(2, 421, 4, 128, dtype=torch.bfloat16)
+    out = fa.flash_attn_func(q.to(DEV), k.to(DEV), v.to(DEV), causal=causal, softcap=softcap)
+    out_ref, out_pt, _ = _dense_ref(q, k, v, causal=causal, softcap=softcap)
+    err = (out.float().cpu() - out_ref.float()).abs().max().item()
+    # rtol 3 with softcap, hopper/test_flash_attn.py:194
+    bound = 3 * (out_pt.float() - out_ref.float()).abs().max().item() + 2 * (out_ref + 0.3 - 0.3 - out_ref).abs().max().item()
+    assert err <= bound, (err, bound)
+
+
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("d", [64, 128])
+@pytest.mark.parametrize("sq,sk", [(1, 147), (113, 203), (128, 217), (512, 512), (1024, 1024)])
+def test_varlen_output(sq, sk, d, causal):
+    """Ragged batches with lengths in [max-20, max] (tests/test_flash_attn.py:58-71,1172-1451)."""
+    fa = _api()
+    from flash_attention_annotated_amd.bert_padding import pad_input, unpad_input
+    torch.manual_seed(4)
+    b, h, hk = 5, 6, 2
+    q = torch.randn(b, sq, h, d, dtype=torch.bfloat16)
+    k = torch.randn(b, sk, hk, d, dtype=torch.bfloat16)
+    v = torch.randn(b, sk, hk, d, dtype=torch.bfloat16)
+    g = torch.Generator().manual_seed(5)
+    qm = torch.arange(sq).view(1, -1) < torch.randint(max(1, sq - 20), sq + 1, (b, 1), generator=g)
+    km = torch.arange(sk).view(1, -1) < torch.randint(max(1, sk - 20), sk + 1, (b, 1), generator=g)
+    qu, iq, cuq, mq, _ = unpad_input(q, qm)
+    ku, _, cuk, mk, _ = unpad_input(k, km)
+    vu = unpad_input(v, km)[0]
+    out_u, lse, _ = fa.flash_attn_varlen_func(qu.to(DEV), ku.to(DEV), vu.to(DEV), cuq.to(DEV), cuk.to(DEV), mq, mk,
+                                              causal=causal, return_attn_probs=True)
+    out = pad_input(out_u.cpu(), iq, b, sq)
+    out_ref, _ = oracle.attention_ref(q, k, v, qm, km, causal=causal)
+    out_pt, _ = oracle.attention_ref(q, k, v, qm, km, causal=causal, upcast=False, reorder_ops=True)
+    _check(out, out_ref, out_pt, f"varlen {sq}x{sk}")
+    # lse (h, total_q) against the per-sequence oracle
+    _, lse_ref = oracle.attention_varlen_ref(qu, ku, vu, cuq, cuk, causal=causal)
+    _check_lse(lse, lse_ref)
+
+
+def test_varlen_zero_length_sequences():
+    """Zero-length key and query sequences inside a batch (hopper/test_flash_attn.py:388-433)."""
+    fa = _api()
+    torch.manual_seed(6)
+    lens_q = [5, 0, 130, 64, 0]
+    lens_k = [7, 33, 0, 300, 0]
+    cuq = torch.tensor([0] + list(torch.tensor(lens_q).cumsum(0)), dtype=torch.int32)
+    cuk = torch.tensor([0] + list(torch.tensor(lens_k).cumsum(0)), dtype=torch.int32)
+    q = torch.randn(sum(lens_q), 4, 64, dtype=torch.bfloat16)
+    k = torch.randn(sum(lens_k), 2, 64, dtype=torch.bfloat16)
+    v = torch.randn(sum(lens_k), 2, 64, dtype=torch.bfloat16)
+    out, lse, _ = fa.flash_attn_varlen_func(q.to(DEV), k.to(DEV), v.to(DEV), cuq.to(DEV), cuk.to(DEV),
+                                            max(lens_q), max(lens_k), return_attn_probs=True)
+    out_ref, lse_ref = oracle.attention_varlen_ref(q, k, v, cuq, cuk)
+    out_pt, _ = oracle.attention_varlen_ref(q, k, v, cuq, cuk, upcast=False, reorder_ops=True)
+    _check(out, out_ref, out_pt, "zero-length")
+    # the sequence with queries but no keys: zero output rows, +inf lse
+    assert torch.all(out[5:135] == 0)
+    _check_lse(lse, lse_ref)
+
+
+def test_strided_views_qkvpacked():
+    """Packed QKV views (row stride 3*h*d) are read in place (flash_attn_interface.py:1008-1062)."""
+    fa = _api()
+    torch.manual_seed(7)
+    qkv = torch.randn(2, 333, 3, 4, 128, dtype=torch.bfloat16)
+    out = fa.flash_attn_qkvpacked_func(qkv.to(DEV), causal=True)
+    out_ref, out_pt, _ = _dense_ref(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], causal=True)
+    _check(out, out_ref, out_pt, "qkvpacked")
+
+
+def test_forward_bitwise_deterministic():
+    """out and lse bit-identical across repeated launches (tests/test_flash_attn.py:2199-2237)."""
+    fa = _api()
+    torch.manual_seed(8)
+    q = torch.randn(2, 1024, 8, 128, dtype=torch.bfloat16, device=DEV)
+    k = torch.randn(2, 1024, 8, 128, dtype=torch.bfloat16, device=DEV)
+    v = torch.randn(2, 1024, 8, 128, dtype=torch.bfloat16, device=DEV)
+    out0, lse0, _ = fa.flash_attn_func(q, k, v, causal=True, return_attn_probs=True)
+    for _ in range(50):
+        out, lse, _ = fa.flash_attn_func(q, k, v, causal=True, return_attn_probs=True)
+        assert torch.equal(out, out0)
+        assert torch.equal(lse, lse0)
+
+
+def test_rescale_branch_forced():
+    """A spike in one late key block forces the running-max rescale on rows that already hold
+    accumulated output (cdna guide rule 26: the rare branch needs its own input)."""
+    fa = _api()
+    torch.manual_seed(9)
+    sq, sk, d = 256, 1024, 128
+    q = torch.randn(1, sq, 2, d, dtype=torch.bfloat16)
+    k = torch.randn(1, sk, 2, d, dtype=torch.bfloat16)
+    v = torch.randn(1, sk, 2, d, dtype=torch.bfloat16)
+    k[0, 700] = q[0, 37] * 3.0      # key 700 (tile 10) dominates row 37 late in the sweep
+    k[0, 1023] = q[0, 200] * 4.0    # last key dominates row 200
+    out, lse, _ = fa.flash_attn_func(q.to(DEV), k.to(DEV), v.to(DEV), return_attn_probs=True)
+    out_ref, out_pt, lse_ref = _dense_ref(q, k, v)
+    _check(out, out_ref, out_pt, "forced rescale")
+    _check_lse(lse, lse_ref, tol=5e-3)
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+def test_kernel_variants_agree(variant):
+    """Every tile shape the dispatcher can pick gives the same answer as the oracle."""
+    from flash_attention_annotated_amd import _lib
+    fa = _api()
+    lib = _lib.load()
+    torch.manual_seed(10)
+    q = torch.randn(2, 777, 4, 128, dtype=torch.bfloat16)
+    k = torch.randn(2, 901, 2, 128, dtype=torch.bfloat16)
+    v = torch.randn(2, 901, 2, 128, dtype=torch.bfloat16)
+    out_ref, out_pt, _ = _dense_ref(q, k, v, causal=True)
+    try:
+        lib.fa_set_default_variant(variant)
+        out = fa.flash_attn_func(q.to(DEV), k.to(DEV), v.to(DEV), causal=True)
+    finally:
+        lib.fa_set_default_variant(0)
+    _check(out, out_ref, out_pt, f"variant {variant}")
+
+
+def test_full_size_properties_c2():
+    """BASELINE config 2 (b4 h16 s8192 d128 bf16) at full size through size-independent properties:
+    (1) a 2-row x all-heads slice equals the oracle computed for those rows only;
+    (2) softmax convexity: every output lies inside [min V, max V] of its kv head;
+    (3) permuting the keys (and values alike) leaves lse unchanged up to fp32 rounding."""
+    fa = _api()
+    torch.manual_seed(0)
+    b, s, h, d = 4, 8192, 16, 128
+    q = torch.randn(b, s, h, d, dtype=torch.bfloat16, device=DEV)
+    k = torch.randn(b, s, h, d, dtype=torch.bfloat16, device=DEV)
+    v = torch.randn(b, s, h, d, dtype=torch.bfloat16, device=DEV)
+    out, lse, _ = fa.flash_attn_func(q, k, v, return_attn_probs=True)
+    assert torch.isfinite(out.float()).all()
+    rows = [0, 4097, 8191]
+    qs = q[:, rows].cpu()
+    out_ref, out_pt, lse_ref = _dense_ref(qs, k.cpu(), v.cpu())
+    _check(out[:, rows], out_ref, out_pt, "c2 slice")
+    _check_lse(lse[:, :, rows], lse_ref)
+    vmin = v.float().amin(dim=1, keepdim=True)
+    vmax = v.float().amax(dim=1, keepdim=True)
+    assert (out.float() >= vmin - 1e-2).all() and (out.float() <= vmax + 1e-2).all()
+    perm = torch.randperm(s, device=DEV)
+    out2, lse2, _ = fa.flash_attn_func(q[:1], k[:1, perm], v[:1, perm], return_attn_probs=True)
+    assert (lse2 - lse[:1]).abs().max().item() < 1e-3
+    assert (out2.float() - out[:1].float()).abs().max().item() < 2e-2
+
+
+def test_error_messages():
+    fa = _api()
+    q = torch.randn(1, 8, 2, 64, dtype=torch.float32, device=DEV)
+    with pytest.raises(RuntimeError, match="only support fp16 and bf16"):
+        fa.flash_attn_func(q, q, q)
+    q = torch.randn(1, 8, 3, 64, dtype=torch.bfloat16, device=DEV)
+    k = torch.randn(1, 8, 2, 64, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(RuntimeError, match="must divide number of heads in query"):
+        fa.flash_attn_func(q, k, k)
+    q = torch.randn(1, 8, 2, 264, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(RuntimeError, match="at most 256"):
+        fa.flash_attn_func(q, q, q)
+
+
+def test_empty_keys_dense():
+    """seqlen_k == 0: out = 0, lse = +inf (csrc/flash_attn/flash_api.cpp:499-504)."""
+    fa = _api()
+    q = torch.randn(1, 8, 2, 64, dtype=torch.bfloat16, device=DEV)
+    k = torch.empty(1, 0, 2, 64, dtype=torch.bfloat16, device=DEV)
+    out, lse, _ = fa.flash_attn_func(q, k, k, return_attn_probs=True)
+    assert torch.all(out == 0) and torch.all(torch.isposinf(lse))
