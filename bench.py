@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""bench.py — attention forward throughput on MI355X (BASELINE.json metric).
+
+A "step" is one pass of the hot path (flash_attn_func / flash_attn_varlen_func -> C-ABI -> HIP kernel)
+over one batch of synthetic tensors already resident in HBM.  Default workload = BASELINE configs[1]
+(C2: batch 4, 16 heads, head dim 128, seq 8192, bf16, non-causal) per GPU; with N GPUs every rank runs
+its own batch shard (no collective on the data path: attention shards over batch) => weak scaling.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4]
+  N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N
+
+Prints ONE JSON line on rank 0 with metric/value/unit (whole-job TFLOP/s), `roofline` (MFMA bound: the
+kernel's algorithmic FLOPs / its HIP-event duration vs the 2.5 PFLOP/s dense bf16 peak) and `cpu_baseline`
+(PyTorch-eager SDPA on the host cores, bounded sample; reported baseline, not a target).
+FLOP convention = the reference's: 4*b*h*sq*sk*d, halved when causal
+(benchmarks/benchmark_flash_attention.py:27-30, hopper/benchmark_attn.py:62-74); softmax not counted.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, MI355X_MICROARCH.md (256 CU x 4 SIMD x 1024 FLOP/clk x 2.4 GHz)
+
+WORKLOADS = {
+    # name: (description, batch, heads_q, heads_kv, seqlen, head_dim, causal, varlen lens or None)
+    "c2": ("C2 b4 h16 d128 s8192 bf16 non-causal", 4, 16, 16, 8192, 128, False, None),
+    "c3": ("C3 b4 h16 d128 s16384 bf16 causal", 4, 16, 16, 16384, 128, True, None),
+    "c4": ("C4 varlen GQA hq32 hkv8 d128 lens 8192..1024 bf16 non-causal", 8, 32, 8, 8192, 128, False,
+           [8192, 7168, 6144, 5120, 4096, 3072, 2048, 1024]),
+}
+
+
+def flops_of(w):
+    _, b, h, hk, s, d, causal, lens = w
+    if lens is not None:
+        f = sum(4 * h * d * L * L for L in lens)
+    else:
+        f = 4 * b * h * s * s * d
+    return f // 2 if causal else f
+
+
+def algorithmic_bytes(w):
+    _, b, h, hk, s, d, causal, lens = w
+    rows = sum(lens) if lens is not None else b * s
+    return 2 * (2 * rows * h * d + 2 * rows * hk * d) + 4 * rows * h  # Q+O, K+V (bf16) + LSE (fp32)
+
+
+def make_inputs(w, device, seed):
+    import torch
+    _, b, h, hk, s, d, causal, lens = w
+    g = torch.Generator(device=device).manual_seed(seed)
+    if lens is None:
+        q = torch.randn(b, s, h, d, device=device, dtype=torch.bfloat16, generator=g)
+        k = torch.randn(b, s, hk, d, device=device, dtype=torch.bfloat16, generator=g)
+        v = torch.randn(b, s, hk, d, device=device, dtype=torch.bfloat16, generator=g)
+        return (q, k, v), {}
+    total = sum(lens)
+    q = torch.randn(total, h, d, device=device, dtype=torch.bfloat16, generator=g)
+    k = torch.randn(total, hk, d, device=device, dtype=torch.bfloat16, generator=g)
+    v = torch.randn(total, hk, d, device=device, dtype=torch.bfloat16, generator=g)
+    cu = torch.tensor([0] + list(__import__("itertools").accumulate(lens)), dtype=torch.int32, device=device)
+    return (q, k, v), {"cu": cu, "max": max(lens)}
+
+
+def cpu_baseline(w, budget_s=20.0):
+    """PyTorch-eager SDPA (fused CPU kernel) on the host cores, on a head-slice of the same workload sized
+    for ~budget_s of CPU work.  Checker/baseline only: imports oracle/, never the other way round."""
+    import torch
+    from oracle.attention_ref import sdpa_cpu
+    name, b, h, hk, s, d, causal, lens = w
+    s_eff = s if lens is None else lens[0]
+    cores = torch.get_num_threads()
+    torch.manual_seed(0)
+
+    def run(nheads):
+        q = torch.randn(1, s_eff, nheads, d, dtype=torch.bfloat16)
+        k = torch.randn(1, s_eff, nheads, d, dtype=torch.bfloat16)
+        v = torch.randn(1, s_eff, nheads, d, dtype=torch.bfloat16)
+        sdpa_cpu(q, k, v, causal)  # warm-up
+        t0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            sdpa_cpu(q, k, v, causal)
+        dt = (time.perf_counter() - t0) / reps
+        fl = 4 * nheads * s_eff * s_eff * d / (2 if causal else 1)
+        return dt, fl
+    dt, fl = run(1)
+    nheads = int(max(1, min(h, budget_s / 4.0 / max(dt, 1e-3))))
+    if nheads > 1:
+        dt, fl = run(nheads)
+    return {
+        "value": round(fl / dt / 1e12, 4), "unit": "TFLOP/s", "cores": cores, "kind": "port",
+        "sample": f"torch SDPA (PyTorch-eager, CPU, bf16) on a (1,{s_eff},{nheads},{d}) slice of the workload, "
+                  f"causal={causal}, 1 warm-up + 3 timed, {dt:.3f} s each, torch.get_num_threads()={cores}",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--variant", type=int, default=0, help="kernel variant override (0 = library default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import flash_attention_annotated_amd as fa
+    from flash_attention_annotated_amd import _lib
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        print(f"bench.py --gpus {args.gpus} must be launched with torch.distributed.run --nproc-per-node {args.gpus}",
+              file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py needs a GPU (the product path has no CPU fallback)", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    lib = _lib.load()
+    if args.variant:
+        lib.fa_set_default_variant(args.variant)
+
+    w = WORKLOADS[args.workload]
+    (q, k, v), extra = make_inputs(w, device, seed=rank)  # each rank: its own batch shard, already in HBM
+
+    def step():
+        if "cu" in extra:
+            return fa.flash_attn_varlen_func(q, k, v, extra["cu"], extra["cu"], extra["max"], extra["max"],
+                                             causal=w[6])
+        return fa.flash_attn_func(q, k, v, causal=w[6])
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+
+    # per-launch kernel durations from HIP events on the launch stream (torch's current stream)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for a, b_ in ev:
+        a.record()
+        step()
+        b_.record()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms = sorted(a.elapsed_time(b_) for a, b_ in ev)
+    avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
+
+    flops = flops_of(w)
+    total_flops = flops * world * args.steps
+    value = total_flops / elapsed / 1e12
+    achieved = flops / (avg_kernel_ms * 1e-3) / 1e12
+
+    if rank == 0:
+        out = {
+            "metric": "attn fwd TFLOPS (aggregate over GPUs; per-GPU in per_gpu) + %MFMA-peak, bf16 hdim128 seq8192",
+            "value": round(value, 2),
+            "unit": "TFLOP/s",
+            "per_gpu": round(value / world, 2),
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "bf16",
+            "data": "synthetic (torch.randn N(0,1), seed = rank)",
+            "config": {"workload": w[0], "batch_per_gpu": w[1], "heads_q": w[2], "heads_kv": w[3], "seqlen": w[4],
+                       "head_dim": w[5], "causal": w[6], "sharding": f"batch shard x{world}, no collective"},
+            "roofline": {
+                "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                "kernel_ms_avg": round(avg_kernel_ms, 4), "kernel_ms_median": round(kernel_ms[len(kernel_ms) // 2], 4),
+                "kernel_ms_min": round(kernel_ms[0], 4), "algorithmic_flops_per_launch": flops,
+                "algorithmic_bytes_per_launch": algorithmic_bytes(w),
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(w)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
