@@ -118,6 +118,9 @@ int fa_fwd_validate(const fa_fwd_params *p) {
                                p->v_row_stride, p->v_head_stride, p->o_row_stride, p->o_head_stride};
     for (int64_t s : strides)
         if (s % 8 != 0) return FA_ERR_BAD_STRIDE;
+    // the kernel addresses a K/V tile as 64-bit tile base + 32-bit (row * stride) lane offset
+    if (p->k_row_stride < 0 || p->v_row_stride < 0 || p->k_row_stride >= (1 << 24) || p->v_row_stride >= (1 << 24))
+        return FA_ERR_BAD_STRIDE;
     if (!p->cu_seqlens_q) {
         const int64_t bs[] = {p->q_batch_stride, p->k_batch_stride, p->v_batch_stride, p->o_batch_stride};
         for (int64_t s : bs)

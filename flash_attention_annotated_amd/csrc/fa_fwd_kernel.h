@@ -110,8 +110,15 @@ __device__ __forceinline__ float fast_tanh(float x) {
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
 }
 
+__device__ __forceinline__ float max3(float a, float b, float c) {
+    // one v_max3_f32; the plain fmaxf chain gets a canonicalising v_max per MFMA output from hipcc
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 template <typename T, int D, int NWAVES, bool SOFTCAP>
-__global__ __launch_bounds__(NWAVES * 64) void fwd_kernel(const KParams p) {
+__global__ __launch_bounds__(NWAVES * 64, (D <= 128 ? 2 : 1)) void fwd_kernel(const KParams p) {
     constexpr int NT = NWAVES * 64;
     constexpr int BLOCK_M = NWAVES * 32;
     constexpr int KSTEPS = D / 16;             // k-steps of the QK^T product
@@ -216,20 +223,31 @@ __global__ __launch_bounds__(NWAVES * 64) void fwd_kernel(const KParams p) {
     float l_run = 0.f;        // running row sum, PARTIAL per lane half (combined in the epilogue)
 
     // ---- K/V staging -------------------------------------------------------------------------
+    // Branch-free loads: a 64-bit wave-uniform tile base plus a 32-bit per-lane offset.  Rows past the
+    // end of the sequence are CLAMPED to the last valid row and head-dim chunks past d to chunk 0
+    // instead of being zero-filled: the duplicated keys are masked to -inf (P = 0) and a duplicated
+    // K chunk meets a zero Q chunk, so finite duplicates contribute exactly 0.  No predication means
+    // no exec-masked branches and no conservative vmcnt waits in front of the MFMAs.
     u32x4 kreg[LD_PER_THREAD], vreg[LD_PER_THREAD];
+    int ld_row[LD_PER_THREAD], ld_col[LD_PER_THREAD];
+#pragma unroll
+    for (int i = 0; i < LD_PER_THREAD; ++i) {
+        const int c = tid + i * NT;
+        ld_row[i] = c / CH_PER_ROW;
+        const int ch = c % CH_PER_ROW;
+        ld_col[i] = (ch * 8 < p.d) ? ch * 8 : 0;
+    }
+    const int k_rs = (int)p.k_row_stride, v_rs = (int)p.v_row_stride;  // host guarantees 64 * stride < 2^31
     auto load_tile = [&](int n) {
+        const int k0 = n * BLOCK_N;
+        const T *kt = kp + (int64_t)k0 * p.k_row_stride;  // scalar
+        const T *vt = vp + (int64_t)k0 * p.v_row_stride;
+        const int last = sk - 1 - k0;                     // >= 0 for every tile in [n_min, n_max)
 #pragma unroll
         for (int i = 0; i < LD_PER_THREAD; ++i) {
-            const int c = tid + i * NT;
-            const int row = c / CH_PER_ROW, ch = c % CH_PER_ROW;
-            const int key = n * BLOCK_N + row;
-            u32x4 kv = {0, 0, 0, 0}, vv = {0, 0, 0, 0};
-            if (key < sk && ch * 8 < p.d) {
-                kv = *(const u32x4 *)(kp + (int64_t)key * p.k_row_stride + ch * 8);
-                vv = *(const u32x4 *)(vp + (int64_t)key * p.v_row_stride + ch * 8);
-            }
-            kreg[i] = kv;
-            vreg[i] = vv;
+            const int row = min(ld_row[i], last);
+            kreg[i] = *(const u32x4 *)(kt + (uint32_t)(row * k_rs + ld_col[i]));
+            vreg[i] = *(const u32x4 *)(vt + (uint32_t)(row * v_rs + ld_col[i]));
         }
     };
     auto store_tile = [&](int buf) {
@@ -251,6 +269,10 @@ __global__ __launch_bounds__(NWAVES * 64) void fwd_kernel(const KParams p) {
         load_tile(n_min);
         store_tile(0);
     }
+    // Retire every prologue load (Q included) here: otherwise hipcc's waitcnt pass keeps Q "pending" on the
+    // loop back-edge and drains vmcnt(0) in front of the first QK^T MFMA of EVERY tile, right after the
+    // next tile's loads were issued.
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     __syncthreads();
 
     for (int n = n_min; n < n_max; ++n) {
@@ -311,11 +333,10 @@ __global__ __launch_bounds__(NWAVES * 64) void fwd_kernel(const KParams p) {
             }
 
             // ---- online softmax (per lane = per query row) ----------------------------------------
-            float mx = fmaxf(s[0][0], s[1][0]);
+            float mx = max3(s[0][0], s[1][0], m_run);
 #pragma unroll
-            for (int i = 1; i < 16; ++i) mx = fmaxf(mx, fmaxf(s[0][i], s[1][i]));
-            mx = half_swap_max(mx);
-            const float m_new = fmaxf(m_run, mx);
+            for (int i = 1; i < 16; ++i) mx = max3(mx, s[0][i], s[1][i]);
+            const float m_new = half_swap_max(mx);  // >= m_run (m_run is identical in both halves)
             const float m_use = (m_new == -INFINITY) ? 0.f : m_new;  // fully masked so far
             const float mc = m_use * p.scale_log2;
             if (__any(m_new > m_run)) {  // wave-uniform; bit-identical to always rescaling
