@@ -86,7 +86,8 @@ class FaFwdParams(ctypes.Structure):
 def build(force=False, verbose=False):
     """Compile csrc/ for gfx950 into the in-tree shared library (hipcc cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, "fa_fwd_api.hip")]
-    deps = srcs + [os.path.join(CSRC, "fa_fwd_kernel.h"), os.path.join(INCLUDE, "fa_fwd.h")]
+    deps = srcs + [os.path.join(CSRC, "fa_fwd_kernel.h"), os.path.join(CSRC, "fa_fwd_kernel_w64.h"),
+                   os.path.join(INCLUDE, "fa_fwd.h")]
     if not force and os.path.exists(LIB_PATH):
         if os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps):
             return LIB_PATH
@@ -113,7 +114,7 @@ def load():
         raise RuntimeError(
             f"{LIB_NAME} is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
             f"(expected at {LIB_PATH}); there is no CPU fallback")
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(os.environ.get("FA_FWD_LIB", LIB_PATH))  # FA_FWD_LIB: developer override (ablation builds)
     lib.fa_fwd.argtypes = [ctypes.POINTER(FaFwdParams), ctypes.c_void_p]
     lib.fa_fwd.restype = ctypes.c_int
     lib.fa_fwd_validate.argtypes = [ctypes.POINTER(FaFwdParams)]
@@ -133,6 +134,8 @@ def load():
         raise RuntimeError("fa_fwd_params layout mismatch between include/fa_fwd.h and _lib.FaFwdParams")
     if lib.fa_abi_version() != FA_ABI_VERSION:
         raise RuntimeError("fa_fwd ABI version mismatch")
+    if os.environ.get("FA_FWD_VARIANT"):  # developer override of the kernel shape (never changes results)
+        lib.fa_set_default_variant(int(os.environ["FA_FWD_VARIANT"]))
     _lib = lib
     return lib
 

@@ -5,6 +5,7 @@
 // pick the instantiation, launch on the caller's stream.  No allocation, no synchronisation.
 #include "fa_fwd.h"
 #include "fa_fwd_kernel.h"
+#include "fa_fwd_kernel_w64.h"
 
 #include <atomic>
 #include <cmath>
@@ -36,14 +37,37 @@ int launch(const fa::KParams &kp, hipStream_t stream) {
     return FA_OK;
 }
 
+template <typename T, int D, bool SOFTCAP>
+int launch_w64(const fa::KParams &kp, hipStream_t stream) {
+    constexpr int smem = fa::smem_bytes_w64<D>();
+    auto kernel = fa::fwd_kernel_w64<T, D, SOFTCAP>;
+    static std::atomic<bool> attr_set{false};
+    if (smem > 65536 && !attr_set.load(std::memory_order_acquire)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) {
+            (void)hipGetLastError();
+            return FA_ERR_LAUNCH;
+        }
+        attr_set.store(true, std::memory_order_release);
+    }
+    hipLaunchKernelGGL(kernel, dim3(kp.num_tiles), dim3(256), smem, stream, kp);
+    if (hipGetLastError() != hipSuccess) return FA_ERR_LAUNCH;
+    return FA_OK;
+}
+
 template <typename T, int D>
 int dispatch_variant(const fa::KParams &kp, bool softcap, int variant, hipStream_t stream) {
-    // variant 0/1: 8 waves x 32 rows (BLOCK_M 256); variant 2: 4 waves x 32 rows (BLOCK_M 128).
-    // D = 256 needs the 512-register budget of one wave per SIMD, so it always takes the 4-wave shape.
+    // variant 0/3: 4 waves x 64 rows, one wave per SIMD, software-pipelined (fa_fwd_kernel_w64.h) -- the default
+    // variant 1  : 8 waves x 32 rows (BLOCK_M 256), two waves per SIMD (fa_fwd_kernel.h)
+    // variant 2  : 4 waves x 32 rows (BLOCK_M 128)
+    // D = 256 does not fit the w64 register budget (O alone would be 256 registers): 4 waves x 32 rows.
     if constexpr (D == 256) {
         if (softcap) return launch<T, D, 4, true>(kp, stream);
         return launch<T, D, 4, false>(kp, stream);
     } else {
+        if (variant == 0 || variant == 3) {
+            if (softcap) return launch_w64<T, D, true>(kp, stream);
+            return launch_w64<T, D, false>(kp, stream);
+        }
         if (variant == 2) {
             if (softcap) return launch<T, D, 4, true>(kp, stream);
             return launch<T, D, 4, false>(kp, stream);
@@ -139,7 +163,7 @@ int fa_fwd(const fa_fwd_params *p, void *stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
 
     int variant = p->kernel_variant ? p->kernel_variant : g_default_variant.load();
-    if (variant < 0 || variant > 2) variant = 0;
+    if (variant < 0 || variant > 3) variant = 0;
     const int block_m = block_m_of(variant, p->d);
 
     fa::KParams kp{};

@@ -63,6 +63,11 @@ template <> struct Elem<__bf16> {
     static __device__ __forceinline__ f32x16 mma(u32x4 a, u32x4 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
     }
+    // accumulate into an AGPR-resident tile: the "+a" constraint pins the accumulator to the AGPR half of the
+    // register file (hipcc otherwise shuttles it through arch VGPRs around every VALU use)
+    static __device__ __forceinline__ void mma_agpr(f32x16 &c, u32x4 a, u32x4 b) {
+        asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    }
     static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
         bf16x2 v = {(__bf16)lo, (__bf16)hi};  // v_cvt_pk_bf16_f32, round-to-nearest-even
         return __builtin_bit_cast(uint32_t, v);
@@ -71,6 +76,9 @@ template <> struct Elem<__bf16> {
 template <> struct Elem<_Float16> {
     static __device__ __forceinline__ f32x16 mma(u32x4 a, u32x4 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void mma_agpr(f32x16 &c, u32x4 a, u32x4 b) {
+        asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
     }
     static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
         f16x2 v = {(_Float16)lo, (_Float16)hi};  // round-to-nearest-even

@@ -1,0 +1,779 @@
+// fa_fwd_kernel_w64.h — gfx950 FlashAttention forward, "one wave per SIMD" mainloop.
+//
+// Same algorithm and LDS images as fa_fwd_kernel.h (transposed scores S^T = K.Q^T with the query row on
+// the lane, O^T = V^T.P^T fed straight from the score accumulators, V^T through ds_read_b64_tr_b16), but a
+// different decomposition, sized for the 512-entry register file a wave owns when it is alone on its SIMD:
+//
+//   * workgroup = 4 waves (one per SIMD), BLOCK_M = 256; each wave owns 64 query rows = two 32-row
+//     q-blocks A and B.  Every K fragment (ds_read_b128) and every V^T fragment (2 x ds_read_b64_tr_b16)
+//     feeds TWO MFMAs (one per q-block): half the LDS read traffic per FLOP of the 32-rows-per-wave shape.
+//   * the 64-key K/V tile is consumed as two 32-key halves.  With nobody else on the SIMD the wave must
+//     overlap its own MFMA and VALU work, so each half-step h is two phases, each one basic block with an
+//     independent MFMA stream and VALU stream of equal weight (16 MFMAs vs one 32x32 softmax):
+//         phase 1   MFMA: S_A(h+1), S_B(h+1) = K(h+1).Q^T         VALU: softmax of S_B(h)  -> P_B(h)
+//         phase 2   MFMA: O_A += V(h)^T.P_A(h), O_B += V(h)^T.P_B(h)   VALU: softmax of S_A(h+1) -> P_A(h+1)
+//     q-block A's softmax runs one half-step ahead of its PV product, so its O rescale is deferred to the
+//     next phase 1 (after the PV MFMAs that still use the old scale have been issued).
+//     Role of the intra-warpgroup overlap of hopper/mainloop_fwd_sm90_tma_gmma_ws.hpp:1170-1207.
+//   * K tiles are staged SHIFTED by 32 keys (K tile m = keys [64m-32, 64m+32)) so that the two score halves
+//     computed during V tile n both come from K tile n+1: K and V are each double-buffered in LDS with one
+//     barrier per 64 keys; global loads for K(n+2)/V(n+1) are issued at the top of tile n and written to LDS
+//     at its end.
+#pragma once
+
+#include "fa_fwd_kernel.h"
+
+#include <type_traits>
+
+namespace fa {
+
+// log2-domain growth of the running max below which O/l are NOT rescaled (the stale max is kept and P may
+// reach 2^THR).  0 = rescale whenever any row's max moves: bit-identical to always rescaling.
+#ifndef FA_RESCALE_THR
+#define FA_RESCALE_THR 8
+#endif
+
+
+// ---- single-instruction helpers (asm so hipcc neither packs them into v_pk_* nor adds canonicalising ops) ----
+__device__ __forceinline__ float add_f32(float a, float b) {
+    float r;
+    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// MFMA wrappers with explicit register classes: S accumulators and Q in arch VGPRs, the O accumulators in AGPRs
+// (only the matrix pipe touches them in the fast loop).
+// hipcc does not pad hazards of asm MFMAs: callers keep >= 1 independent MFMA (or a drain) between an asm
+// MFMA and any VALU reader of its result.
+// Row max of a 32x32 score block over this lane's 16 registers, seeded with m: two v_max3 chains in ONE asm
+// statement (hipcc pads every asm statement boundary with s_nop; one statement = one pad).
+__device__ __forceinline__ void rowmax16(const f32x16 &s, float m, float &mxa, float &mxb) {
+    asm("v_max3_f32 %0, %2, %3, %18\n\t"
+        "v_max3_f32 %1, %4, %5, %18\n\t"
+        "v_max3_f32 %0, %0, %6, %7\n\t"
+        "v_max3_f32 %1, %1, %8, %9\n\t"
+        "v_max3_f32 %0, %0, %10, %11\n\t"
+        "v_max3_f32 %1, %1, %12, %13\n\t"
+        "v_max3_f32 %0, %0, %14, %15\n\t"
+        "v_max3_f32 %1, %1, %16, %17"
+        : "=&v"(mxa), "=&v"(mxb)
+        : "v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(s[3]), "v"(s[4]), "v"(s[5]), "v"(s[6]), "v"(s[7]), "v"(s[8]),
+          "v"(s[9]), "v"(s[10]), "v"(s[11]), "v"(s[12]), "v"(s[13]), "v"(s[14]), "v"(s[15]), "v"(m));
+}
+
+template <typename T> struct Mfma;
+template <> struct Mfma<__bf16> {
+    // PAD variants (generic path): hipcc may put its own VALU / v_accvgpr writes of an operand right in front of
+    // an asm MFMA and pads nothing for asm, so the padded forms carry the 2 wait states themselves.
+    static __device__ __forceinline__ void s_first_pad(f32x16 &d, u32x4 k, u32x4 q) {
+        asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(k), "a"(q));
+    }
+    static __device__ __forceinline__ void s_acc_pad(f32x16 &d, u32x4 k, u32x4 q) {
+        asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(k), "a"(q));
+    }
+    static __device__ __forceinline__ void o_acc_pad(f32x16 &o, u32x4 v, u32x4 pf) {
+        asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(o) : "v"(v), "v"(pf));
+    }
+    static __device__ __forceinline__ void o_zero(f32x16 &o, u32x4 z) {  // O = 0*0 + 0: no VALU/accvgpr write involved
+        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %1, 0" : "=a"(o) : "v"(z));
+    }
+    static __device__ __forceinline__ void s_first(f32x16 &d, u32x4 k, u32x4 q) {
+        asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(k), "a"(q));
+    }
+    static __device__ __forceinline__ void s_acc(f32x16 &d, u32x4 k, u32x4 q) {
+        asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(k), "a"(q));
+    }
+    static __device__ __forceinline__ void o_acc(f32x16 &o, u32x4 v, u32x4 pf) {
+        asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(o) : "v"(v), "v"(pf));
+    }
+    // first PV MFMA of a phase: pads the VALU->MFMA operand hazard in front, and carries the fresh score tiles
+    // as dummy operands so that no VALU reader of them is scheduled before this (independent) MFMA
+    static __device__ __forceinline__ void o_acc_fence(f32x16 &o, u32x4 v, u32x4 pf, f32x16 &s0, f32x16 &s1) {
+        asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %3, %4, %0\n\ts_nop 3"
+            : "+a"(o), "+v"(s0), "+v"(s1) : "v"(v), "v"(pf));
+    }
+};
+template <> struct Mfma<_Float16> {
+    static __device__ __forceinline__ void s_first_pad(f32x16 &d, u32x4 k, u32x4 q) {
+        asm("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(d) : "v"(k), "a"(q));
+    }
+    static __device__ __forceinline__ void s_acc_pad(f32x16 &d, u32x4 k, u32x4 q) {
+        asm("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "v"(k), "a"(q));
+    }
+    static __device__ __forceinline__ void o_acc_pad(f32x16 &o, u32x4 v, u32x4 pf) {
+        asm("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(o) : "v"(v), "v"(pf));
+    }
+    static __device__ __forceinline__ void o_zero(f32x16 &o, u32x4 z) {
+        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %1, 0" : "=a"(o) : "v"(z));
+    }
+    static __device__ __forceinline__ void s_first(f32x16 &d, u32x4 k, u32x4 q) {
+        asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(d) : "v"(k), "a"(q));
+    }
+    static __device__ __forceinline__ void s_acc(f32x16 &d, u32x4 k, u32x4 q) {
+        asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "v"(k), "a"(q));
+    }
+    static __device__ __forceinline__ void o_acc(f32x16 &o, u32x4 v, u32x4 pf) {
+        asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(o) : "v"(v), "v"(pf));
+    }
+    static __device__ __forceinline__ void o_acc_fence(f32x16 &o, u32x4 v, u32x4 pf, f32x16 &s0, f32x16 &s1) {
+        asm("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %3, %4, %0\n\ts_nop 3"
+            : "+a"(o), "+v"(s0), "+v"(s1) : "v"(v), "v"(pf));
+    }
+};
+// LDS-DMA of N consecutive 1-KiB pieces: piece i = 64 lanes x 16 B from (base + off[i]) to LDS byte address
+// lds + 1024 i.  Inline asm on purpose: hipcc cannot prove that the DMA destination does not alias later ds_reads
+// and drains vmcnt(0) right behind a __builtin_amdgcn_global_load_lds, serialising every tile load; asm loads
+// are invisible to its waitcnt pass, and the caller waits (s_waitcnt vmcnt) in front of the barrier that
+// publishes the tile.  M0 (the LDS base of an LDS-DMA) is written and restored inside the statement.
+template <int N>
+__device__ __forceinline__ void lds_dma(uint32_t lds, const void *base, const uint32_t (&off)[N]) {
+    uint32_t keep;
+    static_assert(N == 2 || N == 4, "pieces per wave and tile");
+    if constexpr (N == 4) {
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %6, %1\n\t"
+            "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %7, %1\n\t"
+            "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %8, %1\n\t"
+            "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %9, %1\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "s"(base), "s"(lds), "s"(lds + 1024), "s"(lds + 2048), "s"(lds + 3072), "v"(off[0]), "v"(off[1]),
+              "v"(off[2]), "v"(off[3])
+            : "memory");
+    } else {
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %1\n\t"
+            "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %1\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "s"(base), "s"(lds), "s"(lds + 1024), "v"(off[0]), "v"(off[1])
+            : "memory");
+    }
+}
+// all LDS-DMA of this wave has landed and every wave has reached the end of the tile
+__device__ __forceinline__ void tile_barrier() {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+__device__ __forceinline__ void drain_scores(f32x16 &s0, f32x16 &s1) {
+    // asm MFMA results -> VALU readers (generic path only)
+    asm volatile("s_nop 15\n\ts_nop 7" : "+v"(s0), "+v"(s1));
+}
+
+// Developer-only timing ablations of the fast path (results are WRONG when non-zero; never shipped):
+// 1 = no phase-1 VALU, 2 = no phase-2 VALU, 4 = no K/V loads, 8 = no barriers.
+#ifndef FA_ABLATE
+#define FA_ABLATE 0
+#endif
+
+template <typename T, int D, bool SOFTCAP>
+__global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
+    constexpr int NT = 256;
+    constexpr int BLOCK_M = 256;
+    constexpr int KSTEPS = D / 16;
+    constexpr int DBLOCKS = D / 32;
+    constexpr int CH_PER_ROW = D / 8;
+    constexpr int ROWB = D * 2;                  // bytes per LDS row
+    constexpr int TILE_BYTES = BLOCK_N * ROWB;
+    constexpr int LD_PER_THREAD = BLOCK_N * CH_PER_ROW / NT;
+    constexpr int O_ROW_BYTES = D * 2 + 16;
+    constexpr float THR = (float)FA_RESCALE_THR;
+    static_assert(D == 64 || D == 128, "w64 shape is built for head-dim tiles 64 and 128");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [K0 | K1 | V0 | V1]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31;
+    const int hh = lane >> 5;
+
+    // ---- tile scheduler (XCD-aware), identical to fwd_kernel ------------------------------------------
+    int tile;
+    {
+        const int wg = blockIdx.x;
+        const int nwg = p.num_tiles;
+        const int xcd = wg & 7, slot = wg >> 3;
+        const int q8 = nwg >> 3, r8 = nwg & 7;
+        tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+    }
+    const int mi = tile % p.num_m_blocks;
+    const int bh = tile / p.num_m_blocks;
+    const int m_block = p.num_m_blocks - 1 - mi;
+    const int head = bh % p.h;
+    const int batch = bh / p.h;
+    const int kv_head = head / p.h_ratio;
+
+    int sq, sk;
+    int64_t q_base, k_base, v_base, o_base, lse_base;
+    if (p.cu_seqlens_q) {
+        const int q0 = p.cu_seqlens_q[batch];
+        sq = p.seqused_q ? p.seqused_q[batch] : p.cu_seqlens_q[batch + 1] - q0;
+        q_base = (int64_t)q0 * p.q_row_stride;
+        o_base = (int64_t)q0 * p.o_row_stride;
+        lse_base = (int64_t)head * p.total_q + q0;
+    } else {
+        sq = p.seqused_q ? p.seqused_q[batch] : p.seqlen_q;
+        q_base = (int64_t)batch * p.q_batch_stride;
+        o_base = (int64_t)batch * p.o_batch_stride;
+        lse_base = ((int64_t)batch * p.h + head) * p.seqlen_q;
+    }
+    if (p.cu_seqlens_k) {
+        const int k0 = p.cu_seqlens_k[batch];
+        sk = p.seqused_k ? p.seqused_k[batch] : p.cu_seqlens_k[batch + 1] - k0;
+        k_base = (int64_t)k0 * p.k_row_stride;
+        v_base = (int64_t)k0 * p.v_row_stride;
+    } else {
+        sk = p.seqused_k ? p.seqused_k[batch] : p.seqlen_k;
+        k_base = (int64_t)batch * p.k_batch_stride;
+        v_base = (int64_t)batch * p.v_batch_stride;
+    }
+    const int row_lo = m_block * BLOCK_M;
+    if (row_lo >= sq) return;
+
+    const T *qp = (const T *)p.q + q_base + (int64_t)head * p.q_head_stride;
+    const T *kp = (const T *)p.k + k_base + (int64_t)kv_head * p.k_head_stride;
+    const T *vp = (const T *)p.v + v_base + (int64_t)kv_head * p.v_head_stride;
+    T *op = (T *)p.o + o_base + (int64_t)head * p.o_head_stride;
+
+    const int shift = sk - sq;
+    const int row_hi = min(sq, row_lo + BLOCK_M);
+    int key_hi = sk, key_lo = 0;
+    if (p.window_right >= 0) key_hi = min(sk, row_hi + shift + p.window_right);
+    if (p.window_left >= 0) key_lo = max(0, row_lo + shift - p.window_left);
+    const int n_min = key_lo / BLOCK_N;
+    const int n_max = key_hi > 0 ? (key_hi + BLOCK_N - 1) / BLOCK_N : 0;
+
+    const int wrow = row_lo + wave * 64;  // first row of this wave; q-block A = wrow.., B = wrow+32..
+    const int row_a = wrow + r, row_b = wrow + 32 + r;
+    // half-steps [0, jend) this wave computes (half-step j = keys [64 n_min + 32 j, +32)); later ones are
+    // fully masked for all of its 64 rows (causal / right window).  Waves past the end of q: none.
+    int jend = 2 * (n_max - n_min);
+    if (p.window_right >= 0) {
+        const int last_key = min(sk - 1, wrow + 63 + shift + p.window_right);
+        jend = min(jend, last_key >= n_min * BLOCK_N ? (last_key - n_min * BLOCK_N) / 32 + 1 : 0);
+    }
+    if (wrow >= sq || n_min >= n_max) jend = 0;
+    jend = __builtin_amdgcn_readfirstlane(jend);
+
+    // ---- Q fragments (B operand of S^T = K.Q^T) -------------------------------------------------------
+    u32x4 qa[KSTEPS], qb[KSTEPS];
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+        const int d0 = ks * 16 + hh * 8;
+        u32x4 va = {0, 0, 0, 0}, vb = {0, 0, 0, 0};
+        if (row_a < sq && d0 < p.d) va = *(const u32x4 *)(qp + (int64_t)row_a * p.q_row_stride + d0);
+        if (row_b < sq && d0 < p.d) vb = *(const u32x4 *)(qp + (int64_t)row_b * p.q_row_stride + d0);
+        qa[ks] = va;
+        qb[ks] = vb;
+    }
+    // Q is only ever an MFMA operand: pin it into the AGPR half of the register file (born there, stays there)
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+        asm volatile("; pin Q" : "+a"(qa[ks]));
+        asm volatile("; pin Q" : "+a"(qb[ks]));
+    }
+
+    f32x16 oa[DBLOCKS], ob[DBLOCKS];
+    {
+        const u32x4 z4 = {0, 0, 0, 0};
+#pragma unroll
+        for (int db = 0; db < DBLOCKS; ++db) {
+            Mfma<T>::o_zero(oa[db], z4);
+            Mfma<T>::o_zero(ob[db], z4);
+        }
+    }
+    float m_a = -INFINITY, m_b = -INFINITY;  // running max (unscaled scores)
+    float l_a = 0.f, l_b = 0.f;              // running sums, partial per lane half
+
+    // ---- K/V staging by LDS-DMA (global_load_lds_dwordx4): no staging registers, no ds_write ---------------
+    // One wave-instruction writes 1 KiB = 4 rows x 16 chunks of LDS, lane l -> byte 16 l.  The XOR swizzle of the
+    // LDS image is applied on the SOURCE side: lane l of piece c fetches the chunk that belongs at that slot.
+    // Rows past the end of the sequence are clamped to the last valid row and head-dim chunks past d to chunk 0
+    // (duplicates are masked / meet zero Q chunks: see fa_fwd_kernel.h).  Loads are branch-free.
+    int ld_row[LD_PER_THREAD], ld_col[LD_PER_THREAD];
+    uint32_t koff[LD_PER_THREAD], voff[LD_PER_THREAD];  // byte offsets of this lane's chunks inside an in-range tile
+    const int k_rs = (int)p.k_row_stride, v_rs = (int)p.v_row_stride;
+#pragma unroll
+    for (int i = 0; i < LD_PER_THREAD; ++i) {
+        const int slot = wave * (LD_PER_THREAD * 64) + i * 64 + lane;  // 16-byte slot index inside the tile image
+        const int row = slot / CH_PER_ROW;
+        // inverse of lds_off<D>: the chunk stored at slot position (slot % CH_PER_ROW) of this row
+        int ch;
+        if constexpr (D == 64) ch = (slot % CH_PER_ROW) ^ ((((row >> 1) & 1) << 2) | ((row >> 2) & 3));
+        else ch = (slot % CH_PER_ROW) ^ (((row & 3) << 2) | ((row >> 2) & 3));
+        ld_row[i] = row;
+        ld_col[i] = (ch * 8 < p.d) ? ch * 8 : 0;
+        koff[i] = (uint32_t)(row * k_rs + ld_col[i]) * 2u;
+        voff[i] = (uint32_t)(row * v_rs + ld_col[i]) * 2u;
+    }
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
+    const uint32_t lds_wave = lds0 + wave * (LD_PER_THREAD * 1024);
+    // Tile starting at key k0 (may start before 0 or reach past sk): rows clamped into [0, sk).  The wave-uniform
+    // 64-bit base points at the first clamped row; lane offsets are 32-bit and never negative.
+    auto dma_tile = [&](const T *seq, int row_stride, int64_t row_stride64, const uint32_t (&fast_off)[LD_PER_THREAD],
+                        int k0, uint32_t lds) {
+        const int base_row = min(max(k0, 0), sk - 1);
+        const T *base = seq + (int64_t)base_row * row_stride64;
+        if (k0 >= 0 && k0 + BLOCK_N <= sk) {  // whole tile in range (wave-uniform): precomputed lane offsets
+            lds_dma<LD_PER_THREAD>(lds, base, fast_off);
+        } else {
+            uint32_t off[LD_PER_THREAD];
+#pragma unroll
+            for (int i = 0; i < LD_PER_THREAD; ++i) {
+                const int rel = min(max(k0 + ld_row[i], 0), sk - 1) - base_row;  // 0..63
+                off[i] = (uint32_t)(rel * row_stride + ld_col[i]) * 2u;
+            }
+            lds_dma<LD_PER_THREAD>(lds, base, off);
+        }
+    };
+    // K tile m = keys [64m - 32, 64m + 32)
+    auto load_k = [&](int m, int buf) { dma_tile(kp, k_rs, p.k_row_stride, koff, m * BLOCK_N - 32, lds_wave + buf * TILE_BYTES); };
+    auto load_v = [&](int n, int buf) { dma_tile(vp, v_rs, p.v_row_stride, voff, n * BLOCK_N, lds_wave + (2 + buf) * TILE_BYTES); };
+
+    // ---- lane parts of the LDS read addresses; everything else is an immediate or one XOR ---------------
+    const int i16 = lane & 15, g1 = (lane >> 4) & 1;
+    const int kbase = lds_off<D>(r, hh);                                            // ^ 32*ks, + half/buffer
+    const int vbase = lds_off<D>(4 * hh + (i16 >> 2), 2 * g1 + ((i16 >> 1) & 1)) + 8 * (i16 & 1);  // ^ (64 db + 32 j2)
+
+    // S(half kh of the K tile in buffer kbuf) for both q-blocks; every K fragment feeds two MFMAs
+    auto qk_half = [&](int kbuf, int kh, f32x16 &sa, f32x16 &sb) {
+        const char *base = smem + kbuf * TILE_BYTES + kh * (32 * ROWB);
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const u32x4 kf = *(const u32x4 *)(base + (kbase ^ (32 * ks)));
+            if (ks == 0) {
+                Mfma<T>::s_first_pad(sa, kf, qa[ks]);
+                Mfma<T>::s_first_pad(sb, kf, qb[ks]);
+            } else {
+                Mfma<T>::s_acc_pad(sa, kf, qa[ks]);
+                Mfma<T>::s_acc_pad(sb, kf, qb[ks]);
+            }
+        }
+    };
+    // O^T += V^T.P^T over half kh of the V tile in buffer vbuf; every V^T fragment feeds two MFMAs.
+    // Element j of lane half hh of 16-key step st is key 16st + 8(j>>2) + 4hh + (j&3).
+    // s0/s1: the score tiles written by the preceding asm MFMAs (fenced behind the first MFMA issued here).
+    auto pv_half = [&](int vbuf, int kh, const u32x4 (&pa)[2], const u32x4 (&pb)[2], f32x16 &s0, f32x16 &s1) {
+        const char *base = smem + (2 + vbuf) * TILE_BYTES + kh * (32 * ROWB);
+#pragma unroll
+        for (int db = 0; db < DBLOCKS; ++db) {
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                u32x4 vf;
+#pragma unroll
+                for (int j2 = 0; j2 < 2; ++j2) {
+                    const s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(
+                        base + (vbase ^ (64 * db + 32 * j2)) + (16 * st + 8 * j2) * ROWB));
+                    const u32x2 t2 = __builtin_bit_cast(u32x2, t);
+                    vf[2 * j2] = t2[0];
+                    vf[2 * j2 + 1] = t2[1];
+                }
+                if (db == 0 && st == 0) Mfma<T>::o_acc_fence(oa[db], vf, pa[st], s0, s1);
+                else Mfma<T>::o_acc_pad(oa[db], vf, pa[st]);
+                Mfma<T>::o_acc_pad(ob[db], vf, pb[st]);
+            }
+        }
+    };
+    // softcap + mask of a fresh score half (j = half-step index); mask only on boundary halves
+    auto half_needs_mask = [&](int j) -> bool {
+        const int k0 = n_min * BLOCK_N + 32 * j;
+        bool need = (k0 + 32 > sk);
+        if (p.window_right >= 0) need = need || (k0 + 31 > wrow + shift + p.window_right);
+        if (p.window_left >= 0) need = need || (k0 < wrow + 63 + shift - p.window_left);
+        return need;
+    };
+    auto prep_scores = [&](int j, f32x16 &sa, f32x16 &sb) {
+        if constexpr (SOFTCAP) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                sa[i] = fast_tanh(sa[i] * p.softcap_pre);
+                sb[i] = fast_tanh(sb[i] * p.softcap_pre);
+            }
+        }
+        if (half_needs_mask(j)) {
+            const int k0 = n_min * BLOCK_N + 32 * j + 4 * hh;
+            int hi_a = sk, hi_b = sk, lo_a = 0, lo_b = 0;  // [lo, hi) visible
+            if (p.window_right >= 0) {
+                hi_a = min(sk, row_a + shift + p.window_right + 1);
+                hi_b = min(sk, row_b + shift + p.window_right + 1);
+            }
+            if (p.window_left >= 0) {
+                lo_a = max(0, row_a + shift - p.window_left);
+                lo_b = max(0, row_b + shift - p.window_left);
+            }
+            hi_a -= k0; hi_b -= k0; lo_a -= k0; lo_b -= k0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int key = (i & 3) + 8 * (i >> 2);
+                if (key >= hi_a || key < lo_a) sa[i] = -INFINITY;
+                if (key >= hi_b || key < lo_b) sb[i] = -INFINITY;
+            }
+        }
+    };
+    // online softmax of one 32x32 score block; lane = query row.  Writes P^T fragments (the B operand of
+    // the PV product), updates (m, l); alpha = factor the O accumulator still has to be multiplied with.
+    auto softmax = [&](f32x16 &s, u32x4 (&pf)[2], float &m_run, float &l_run, float &alpha, bool &moved) {
+        float mxa, mxb;
+        rowmax16(s, m_run, mxa, mxb);
+        const float m_new = half_swap_max(fmaxf(mxa, mxb));  // >= m_run, identical in both lane halves
+        float m_eff;
+        if constexpr (THR == 0.f) {
+            moved = __any(m_new > m_run);
+            m_eff = m_new;
+        } else {
+            moved = __any((m_new - m_run) * p.scale_log2 > THR);  // -inf -> finite counts as moved
+            m_eff = moved ? m_new : m_run;
+        }
+        const float mc = (m_eff == -INFINITY ? 0.f : m_eff) * p.scale_log2;
+        alpha = __builtin_amdgcn_exp2f(m_run * p.scale_log2 - mc);
+        m_run = m_eff;
+        float ps0 = 0.f, ps1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) {
+            const float a = __builtin_amdgcn_exp2f(s[i] * p.scale_log2 - mc);
+            const float b = __builtin_amdgcn_exp2f(s[i + 1] * p.scale_log2 - mc);
+            s[i] = a;
+            s[i + 1] = b;
+            ps0 = add_f32(ps0, a);
+            ps1 = add_f32(ps1, b);
+        }
+        l_run = l_run * alpha + (ps0 + ps1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            pf[0][j] = Elem<T>::pack2(s[2 * j], s[2 * j + 1]);
+            pf[1][j] = Elem<T>::pack2(s[8 + 2 * j], s[8 + 2 * j + 1]);
+        }
+    };
+    // wave-uniform: would softmax of this block move some row's running max by more than THR?
+    auto max_would_move = [&](const f32x16 &s, float m_run) -> bool {
+        float mxa, mxb;
+        rowmax16(s, m_run, mxa, mxb);
+        const float m_new = half_swap_max(fmaxf(mxa, mxb));
+        return __any((m_new - m_run) * p.scale_log2 > THR);
+    };
+    // exp/sum/pack with the running max left where it is (caller has checked max_would_move == false)
+    auto softmax_keep_max = [&](f32x16 &s, u32x4 (&pf)[2], float m_run, float &l_run) {
+        const float mc = (m_run == -INFINITY ? 0.f : m_run) * p.scale_log2;
+        float ps0 = 0.f, ps1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) {
+            const float a = __builtin_amdgcn_exp2f(s[i] * p.scale_log2 - mc);
+            const float b = __builtin_amdgcn_exp2f(s[i + 1] * p.scale_log2 - mc);
+            s[i] = a;
+            s[i + 1] = b;
+            ps0 = add_f32(ps0, a);
+            ps1 = add_f32(ps1, b);
+        }
+        l_run += ps0 + ps1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            pf[0][j] = Elem<T>::pack2(s[2 * j], s[2 * j + 1]);
+            pf[1][j] = Elem<T>::pack2(s[8 + 2 * j], s[8 + 2 * j + 1]);
+        }
+    };
+    // Rare path (a running max grew by more than THR).  O lives in AGPRs and is written by asm MFMAs whose
+    // result hazard hipcc does not pad: drain the matrix pipe, with the accumulators as operands of the
+    // drain so no reader can be scheduled above it.
+    auto drain_mfma = [&](f32x16 (&o)[DBLOCKS]) {
+        if constexpr (DBLOCKS == 4)
+            asm volatile("s_nop 15\n\ts_nop 7" : "+a"(o[0]), "+a"(o[1]), "+a"(o[2]), "+a"(o[3]));
+        else
+            asm volatile("s_nop 15\n\ts_nop 7" : "+a"(o[0]), "+a"(o[1]));
+    };
+    auto rescale = [&](f32x16 (&o)[DBLOCKS], float alpha) {
+        drain_mfma(o);
+#pragma unroll
+        for (int db = 0; db < DBLOCKS; ++db)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[db][i] *= alpha;
+        drain_mfma(o);  // VALU / accvgpr writes -> next MFMA reading them as SrcC
+    };
+
+    // ---- prologue: K tiles n_min and n_min+1, V tile n_min; first scores; softmax of A(0) -------------
+    if (n_min < n_max) {
+        load_k(n_min, 0);
+        load_v(n_min, 0);
+        load_k(n_min + 1, 1);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): Q has landed; nothing compiler-visible stays pending
+    tile_barrier();                      // first tiles landed (asm LDS-DMA) and visible to every wave
+
+    // Pipeline state at the boundary in front of half-step j (canonical naming):
+    //   sbx = S_B(j) (masked, not yet exponentiated), pax = P_A(j), (m_a, l_a) through j, (m_b, l_b) through
+    //   j-1, and O_A still owes the factor alpha_a when moved_a.
+    f32x16 sa, sbx, sby;
+    u32x4 pax[2], pay[2], pb[2];
+    float alpha_a = 1.f, alpha_b = 1.f;
+    bool moved_a = false, moved_b = false;
+    if (jend > 0) {
+        qk_half(0, 1, sa, sbx);  // half-step 0 = second half of K tile n_min
+        drain_scores(sa, sbx);
+        prep_scores(0, sa, sbx);
+        softmax(sa, pax, m_a, l_a, alpha_a, moved_a);
+        moved_a = false;  // O_A is still zero: nothing to rescale
+    }
+    __syncthreads();  // every wave has read K tile n_min before tile n_min's end overwrites its buffer
+
+    const int J = 2 * (n_max - n_min);
+    // ---- generic half-step: any boundary case (masks, last half-steps of the wave, rescales) --------------
+    auto generic_half = [&](int j) {
+        const int i = j >> 1, kb = j & 1, slot = i & 1, n = n_min + i;
+        if (kb == 0) {  // K tile n+2 over K tile n, V tile n+1 over V tile n-1 (both last read during tile n-1)
+            if (n + 2 <= n_max) load_k(n + 2, slot);
+            if (n + 1 < n_max) load_v(n + 1, slot ^ 1);
+        }
+        if (j < jend) {
+            if (moved_a) rescale(oa, alpha_a);  // deferred from softmax A(j)
+            moved_a = false;
+            if (j + 1 < jend) {
+                qk_half(slot ^ 1, kb, sa, sby);
+                softmax(sbx, pb, m_b, l_b, alpha_b, moved_b);
+                if (moved_b) rescale(ob, alpha_b);
+                drain_scores(sa, sby);
+                prep_scores(j + 1, sa, sby);
+                pv_half(slot, kb, pax, pb, sa, sby);
+                softmax(sa, pay, m_a, l_a, alpha_a, moved_a);
+                sbx = sby;
+                pax[0] = pay[0];
+                pax[1] = pay[1];
+            } else {
+                softmax(sbx, pb, m_b, l_b, alpha_b, moved_b);
+                if (moved_b) rescale(ob, alpha_b);
+                pv_half(slot, kb, pax, pb, sa, sby);
+            }
+        }
+        if (kb == 1) tile_barrier();  // this tile's LDS-DMA has landed; every wave is done with the old buffers
+    };
+    // ---- fast half-step: interior of the sweep.  No masks, a next half-step exists, and no running max
+    //      moves (checked one half-step ahead), so O is touched by nothing but the AGPR-pinned MFMAs.
+    //      Hand-placed schedule: the wave is alone on its SIMD and issues in order, so every pair of MFMAs is
+    //      followed by a fixed slice of the softmax VALU work (one v_exp per MFMA gap) and the slices are pinned
+    //      with sched_barrier.  Returns true when the NEXT half-step needs the generic path. ------------------
+    auto fast_half = [&](auto slot_c, auto kb_c, f32x16 &sb_cur, f32x16 &sb_nxt, u32x4 (&pa_cur)[2],
+                         u32x4 (&pa_nxt)[2]) -> bool {
+        constexpr int SLOT = decltype(slot_c)::value, KB = decltype(kb_c)::value;
+        const char *kb_base = smem + (SLOT ^ 1) * TILE_BYTES + KB * (32 * ROWB);
+        const char *vb_base = smem + (2 + SLOT) * TILE_BYTES + KB * (32 * ROWB);
+        auto k_frag = [&](int ks) { return *(const u32x4 *)(kb_base + (kbase ^ (32 * ks))); };
+        auto v_frag = [&](int t) {  // step t = (db, st)
+            const int db = t >> 1, st = t & 1;
+            u32x4 vf;
+#pragma unroll
+            for (int j2 = 0; j2 < 2; ++j2) {
+                const s16x4 x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(
+                    vb_base + (vbase ^ (64 * db + 32 * j2)) + (16 * st + 8 * j2) * ROWB));
+                const u32x2 x2 = __builtin_bit_cast(u32x2, x);
+                vf[2 * j2] = x2[0];
+                vf[2 * j2 + 1] = x2[1];
+            }
+            return vf;
+        };
+        const float csc = p.scale_log2;
+
+        // ---------- phase 1: S(j+1) = K.Q^T on the matrix pipe || exp/sum/pack of B(j) on the VALU ----------
+        // LDS fragments are fetched two slices (>= 128 cycles) ahead of the MFMA that consumes them; the first
+        // two V^T fragments of phase 2 are fetched during the last two slices of phase 1.
+        u32x4 vfa, vfb;  // V^T fragments handed from phase 1 to phase 2
+        {
+            constexpr int PER = 16 / KSTEPS;  // score elements of B(j) finished per k-step
+            const float mcb = (m_b == -INFINITY ? 0.f : m_b) * csc;
+            float ps0 = 0.f, ps1 = 0.f;
+            u32x4 kf0 = k_frag(0), kf1 = k_frag(1);
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+                u32x4 kf2 = kf1;
+                if (ks + 2 < KSTEPS) kf2 = k_frag(ks + 2);
+                else if (ks + 2 == KSTEPS) vfa = v_frag(0);
+                else vfb = v_frag(1);
+                if (ks == 0) {
+                    Mfma<T>::s_first(sa, kf0, qa[0]);
+                    Mfma<T>::s_first(sb_nxt, kf0, qb[0]);
+                } else {
+                    Mfma<T>::s_acc(sa, kf0, qa[ks]);
+                    Mfma<T>::s_acc(sb_nxt, kf0, qb[ks]);
+                }
+#pragma unroll
+                for (int e = ks * PER; e < (ks + 1) * PER && !(FA_ABLATE & 1); e += 2) {
+                    const float x = __builtin_amdgcn_exp2f(sb_cur[e] * csc - mcb);
+                    const float y = __builtin_amdgcn_exp2f(sb_cur[e + 1] * csc - mcb);
+                    ps0 = add_f32(ps0, x);
+                    ps1 = add_f32(ps1, y);
+                    pb[e >> 3][(e & 7) >> 1] = Elem<T>::pack2(x, y);
+                }
+                kf0 = kf1;
+                kf1 = kf2;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            l_b += ps0 + ps1;
+        }
+
+        // ---------- phase 2: O += V^T.P^T on the matrix pipe || softmax of A(j+1) + max look-ahead of B(j+1) ----
+        bool b_moves;
+        {
+            constexpr int NSTEP = 2 * DBLOCKS;      // (db, st) steps, two MFMAs each
+            constexpr int CPS = 8 / NSTEP;          // VALU chunks per step (8 chunks in all)
+            float mxa = 0.f, mxb = 0.f, nxa = 0.f, nxb = 0.f, mca = 0.f, ps0 = 0.f, ps1 = 0.f, m_new_b = 0.f;
+            auto exp_a = [&](int e0, int e1) {  // elements [e0, e1) of A, e0 even
+#pragma unroll
+                for (int e = e0; e < e1; e += 2) {
+                    const float x = __builtin_amdgcn_exp2f(sa[e] * csc - mca);
+                    const float y = __builtin_amdgcn_exp2f(sa[e + 1] * csc - mca);
+                    ps0 = add_f32(ps0, x);
+                    ps1 = add_f32(ps1, y);
+                    pa_nxt[e >> 3][(e & 7) >> 1] = Elem<T>::pack2(x, y);
+                }
+            };
+            auto chunk = [&](int c) {
+                if (c == 0) {  // row max of A(j+1)
+                    rowmax16(sa, m_a, mxa, mxb);
+                } else if (c == 1) {  // decide, rescale factors
+                    const float m_new = half_swap_max(fmaxf(mxa, mxb));
+                    moved_a = __any((m_new - m_a) * csc > THR);
+                    const float m_eff = moved_a ? m_new : m_a;
+                    mca = (m_eff == -INFINITY ? 0.f : m_eff) * csc;
+                    alpha_a = __builtin_amdgcn_exp2f(m_a * csc - mca);
+                    m_a = m_eff;
+                } else if (c == 2) {
+                    exp_a(0, 2);
+                    rowmax16(sb_nxt, m_b, nxa, nxb);
+                } else if (c == 3) {
+                    exp_a(2, 6);
+                } else if (c == 4) {
+                    exp_a(6, 10);
+                    m_new_b = half_swap_max(fmaxf(nxa, nxb));
+                } else if (c == 5) {
+                    exp_a(10, 12);
+                } else if (c == 6) {
+                    exp_a(12, 14);
+                } else {
+                    exp_a(14, 16);
+                }
+            };
+            u32x4 vf = vfa, vf_next = vfb;
+#pragma unroll
+            for (int t = 0; t < NSTEP; ++t) {
+                u32x4 vf_next2 = vf_next;
+                if (t + 2 < NSTEP) vf_next2 = v_frag(t + 2);
+                const int db = t >> 1, st = t & 1;
+                if (t == 0) Mfma<T>::o_acc_fence(oa[db], vf, pa_cur[st], sa, sb_nxt);
+                else Mfma<T>::o_acc(oa[db], vf, pa_cur[st]);
+                Mfma<T>::o_acc(ob[db], vf, pb[st]);
+#pragma unroll
+                for (int c = t * CPS; c < (t + 1) * CPS && !(FA_ABLATE & 2); ++c) chunk(c);
+                vf = vf_next;
+                vf_next = vf_next2;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            l_a = l_a * alpha_a + (ps0 + ps1);
+            b_moves = __any((m_new_b - m_b) * csc > THR);
+        }
+        return moved_a || b_moves;
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+
+    // last half-step index whose scores need no mask (for this wave), and the fast limit: every half-step
+    // jj of a fast tile pair [j, j+4) needs jj + 1 <= fast_last
+    int fast_last = -1;
+    if (!SOFTCAP && p.window_left < 0 && jend > 0) {
+        int nomask = (sk - n_min * BLOCK_N) / 32 - 1;
+        if (p.window_right >= 0) {
+            const int t = wrow + shift + p.window_right - 31 - n_min * BLOCK_N;
+            nomask = min(nomask, t >= 0 ? t / 32 : -1);
+        }
+        fast_last = min(nomask, jend - 1);
+    }
+    fast_last = __builtin_amdgcn_readfirstlane(fast_last);
+
+    int j = 0;
+    while (j < J) {
+        // generic until the next tile-pair boundary (at least one half-step: guarantees progress)
+        do {
+            generic_half(j);
+            ++j;
+        } while ((j & 3) != 0 && j < J);
+        if (j + 4 > fast_last || moved_a || max_would_move(sbx, m_b)) continue;
+        // fast tile pairs
+        while (j + 4 <= fast_last) {
+            const int n = n_min + (j >> 1);
+            if (!(FA_ABLATE & 4)) {
+                load_k(n + 2, 0);
+                load_v(n + 1, 1);
+            }
+            if (fast_half(I0{}, I0{}, sbx, sby, pax, pay)) {
+                sbx = sby; pax[0] = pay[0]; pax[1] = pay[1];
+                j += 1;
+                break;
+            }
+            const bool x1 = fast_half(I0{}, I1{}, sby, sbx, pay, pax);
+            if (!(FA_ABLATE & 8)) tile_barrier();
+            if (x1) { j += 2; break; }
+            if (!(FA_ABLATE & 4)) {
+                load_k(n + 3, 1);
+                load_v(n + 2, 0);
+            }
+            if (fast_half(I1{}, I0{}, sbx, sby, pax, pay)) {
+                sbx = sby; pax[0] = pay[0]; pax[1] = pay[1];
+                j += 3;
+                break;
+            }
+            const bool x3 = fast_half(I1{}, I1{}, sby, sbx, pay, pax);
+            if (!(FA_ABLATE & 8)) tile_barrier();
+            j += 4;
+            if (x3) break;
+        }
+    }
+
+    // ---- epilogue ---------------------------------------------------------------------------------------
+    drain_mfma(oa);  // asm MFMA results -> VALU readers
+    drain_mfma(ob);
+    const float lt_a = half_swap_sum(l_a), lt_b = half_swap_sum(l_b);
+    const bool e_a = (lt_a == 0.f) || (lt_a != lt_a), e_b = (lt_b == 0.f) || (lt_b != lt_b);
+    const float inv_a = e_a ? 1.f : 1.f / lt_a, inv_b = e_b ? 1.f : 1.f / lt_b;
+    const bool wave_active = wrow < sq;
+    if (wave_active) {
+        if (hh == 0) {
+            if (row_a < sq) p.lse[lse_base + row_a] = e_a ? INFINITY : m_a * p.scale + __logf(lt_a);
+            if (row_b < sq) p.lse[lse_base + row_b] = e_b ? INFINITY : m_b * p.scale + __logf(lt_b);
+        }
+        char *obuf = smem + wave * (64 * O_ROW_BYTES);
+#pragma unroll
+        for (int db = 0; db < DBLOCKS; ++db)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                u32x2 wa, wb;
+                wa[0] = Elem<T>::pack2(oa[db][4 * g4] * inv_a, oa[db][4 * g4 + 1] * inv_a);
+                wa[1] = Elem<T>::pack2(oa[db][4 * g4 + 2] * inv_a, oa[db][4 * g4 + 3] * inv_a);
+                wb[0] = Elem<T>::pack2(ob[db][4 * g4] * inv_b, ob[db][4 * g4 + 1] * inv_b);
+                wb[1] = Elem<T>::pack2(ob[db][4 * g4 + 2] * inv_b, ob[db][4 * g4 + 3] * inv_b);
+                const int col = (db * 32 + 8 * g4 + 4 * hh) * 2;
+                *(u32x2 *)(obuf + r * O_ROW_BYTES + col) = wa;
+                *(u32x2 *)(obuf + (32 + r) * O_ROW_BYTES + col) = wb;
+            }
+    }
+    __syncthreads();
+    if (wave_active) {
+        const char *obuf = smem + wave * (64 * O_ROW_BYTES);
+#pragma unroll
+        for (int i = 0; i < (64 * CH_PER_ROW) / 64; ++i) {
+            const int c = lane + i * 64;
+            const int row = c / CH_PER_ROW, ch = c % CH_PER_ROW;
+            if (wrow + row < sq && ch * 8 < p.d) {
+                const u32x4 val = *(const u32x4 *)(obuf + row * O_ROW_BYTES + ch * 16);
+                *(u32x4 *)(op + (int64_t)(wrow + row) * p.o_row_stride + ch * 8) = val;
+            }
+        }
+    }
+}
+
+template <int D>
+constexpr int smem_bytes_w64() {
+    constexpr int kv = 4 * BLOCK_N * D * 2;
+    constexpr int o = 4 * 64 * (D * 2 + 16);
+    return kv > o ? kv : o;
+}
+
+}  // namespace fa

@@ -1,0 +1,68 @@
+"""Scan a hipcc -S dump for MFMA operand hazards the compiler does not pad around inline-asm MFMAs.
+
+Rule checked (cdna guide §5.7 item 2): a VGPR/AGPR written by a VALU instruction (v_cvt*, v_mov, v_accvgpr_*, ...)
+must not be read by a v_mfma as SrcA/SrcB/SrcC within the next 2 wait states.  Every instruction in between
+counts one wait state, `s_nop N` counts N+1.  MFMA->MFMA accumulate chains are exempt (hardware interlocked).
+Usage: python tools/isa_hazards.py file.s  -> prints violations, exit code 1 if any.
+"""
+import re
+import sys
+
+REQUIRED = 2  # the guide's figure; the scan is run with a margin (see tests/test_isa_hazards.py)
+
+
+def regs(tok):
+    tok = tok.strip()
+    m = re.match(r'^([va])\[(\d+):(\d+)\]$', tok)
+    if m:
+        return {(m.group(1), i) for i in range(int(m.group(2)), int(m.group(3)) + 1)}
+    m = re.match(r'^([va])(\d+)$', tok)
+    if m:
+        return {(m.group(1), int(m.group(2)))}
+    return set()
+
+
+def scan(path, required=REQUIRED):
+    violations = []
+    kernel = None
+    window = []  # (states_so_far_after, dst_regs, text, lineno) of recent VALU writes
+    for lineno, raw in enumerate(open(path), 1):
+        l = raw.strip()
+        m = re.match(r'^(_Z\w+):', l)
+        if m:
+            kernel = m.group(1)
+            window = []
+            continue
+        if not l or l.startswith(';') or l.startswith('.') or l.endswith(':'):
+            continue
+        op = l.split()[0]
+        if op.startswith('v_mfma'):
+            ops = l.split(None, 1)[1].split(',')
+            srcs = set()
+            for t in ops[1:]:
+                srcs |= regs(t)
+            for dist, dst, text, ln in window:
+                if dist < required and (dst & srcs):
+                    violations.append((kernel, ln, text, lineno, l, dist))
+            states = 1
+            new_w = []
+        else:
+            states = 1
+            if op == 's_nop':
+                states = int(l.split()[1]) + 1
+            elif op in ('s_waitcnt', 's_barrier') or op.startswith(';'):
+                states = 0  # may retire without spending an issue cycle: do not count on it
+        # age the window
+        window = [(d + states, dst, t, ln) for d, dst, t, ln in window if d + states < required + 1]
+        if op.startswith('v_') and not op.startswith('v_mfma') and not op.startswith('v_cmp'):
+            dst = regs(l.split(None, 1)[1].split(',')[0]) if ' ' in l else set()
+            window.append((0, dst, l, lineno))
+    return violations
+
+
+if __name__ == '__main__':
+    v = scan(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else REQUIRED)
+    for k, ln, text, ln2, mf, dist in v:
+        print(f"{k}: line {ln}: `{text}` -> line {ln2}: `{mf}` ({dist} wait states between)")
+    print(f"{len(v)} violation(s)")
+    sys.exit(1 if v else 0)
