@@ -34,12 +34,47 @@ namespace fa {
 #endif
 
 
-// ---- single-instruction helpers (asm so hipcc neither packs them into v_pk_* nor adds canonicalising ops) ----
-__device__ __forceinline__ float add_f32(float a, float b) {
-    float r;
-    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
+// ---- softmax inner step for two scores in ONE asm statement --------------------------------------------------
+//   x = exp2(s0*c - mc), y = exp2(s1*c - mc);  ps0 += x;  ps1 += y;  returns pack(x, y) in the input dtype (RNE)
+// Written in asm as a unit because (a) gfx950 needs one wait state between a transcendental (v_exp) and a
+// non-transcendental VALU reader of its result, which hipcc pads only for its own instructions -- the order
+// exp,exp,add,add,cvt keeps one instruction between every producer/consumer pair; (b) it keeps hipcc from packing
+// the adds into v_pk_add_f32 (slow beside MFMAs) and (c) one statement = one asm boundary pad.
+template <typename T> struct Exp2Pair;
+template <> struct Exp2Pair<__bf16> {
+    static __device__ __forceinline__ uint32_t run(float s0, float s1, float c, float mc, float &ps0, float &ps1) {
+        uint32_t pk;
+        float t0, t1;
+        asm("v_fma_f32 %3, %5, %7, -%8\n\t"
+            "v_fma_f32 %4, %6, %7, -%8\n\t"
+            "v_exp_f32 %3, %3\n\t"
+            "v_exp_f32 %4, %4\n\t"
+            "v_add_f32 %1, %1, %3\n\t"
+            "v_add_f32 %2, %2, %4\n\t"
+            "v_cvt_pk_bf16_f32 %0, %3, %4"
+            : "=&v"(pk), "+v"(ps0), "+v"(ps1), "=&v"(t0), "=&v"(t1)
+            : "v"(s0), "v"(s1), "s"(c), "v"(mc));
+        return pk;
+    }
+};
+template <> struct Exp2Pair<_Float16> {
+    static __device__ __forceinline__ uint32_t run(float s0, float s1, float c, float mc, float &ps0, float &ps1) {
+        uint32_t pk;
+        float t0, t1;
+        asm("v_fma_f32 %3, %5, %7, -%8\n\t"
+            "v_fma_f32 %4, %6, %7, -%8\n\t"
+            "v_exp_f32 %3, %3\n\t"
+            "v_exp_f32 %4, %4\n\t"
+            "v_add_f32 %1, %1, %3\n\t"
+            "v_add_f32 %2, %2, %4\n\t"
+            "v_cvt_f16_f32 %3, %3\n\t"
+            "v_cvt_f16_f32 %4, %4\n\t"
+            "v_pack_b32_f16 %0, %3, %4"
+            : "=&v"(pk), "+v"(ps0), "+v"(ps1), "=&v"(t0), "=&v"(t1)
+            : "v"(s0), "v"(s1), "s"(c), "v"(mc));
+        return pk;
+    }
+};
 
 // MFMA wrappers with explicit register classes: S accumulators and Q in arch VGPRs, the O accumulators in AGPRs
 // (only the matrix pipe touches them in the fast loop).
@@ -431,21 +466,11 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
         alpha = __builtin_amdgcn_exp2f(m_run * p.scale_log2 - mc);
         m_run = m_eff;
         float ps0 = 0.f, ps1 = 0.f;
+        const float csc = p.scale_log2;  // kernarg: wave-uniform, lives in an SGPR
 #pragma unroll
-        for (int i = 0; i < 16; i += 2) {
-            const float a = __builtin_amdgcn_exp2f(s[i] * p.scale_log2 - mc);
-            const float b = __builtin_amdgcn_exp2f(s[i + 1] * p.scale_log2 - mc);
-            s[i] = a;
-            s[i + 1] = b;
-            ps0 = add_f32(ps0, a);
-            ps1 = add_f32(ps1, b);
-        }
+        for (int i = 0; i < 16; i += 2)
+            pf[i >> 3][(i & 7) >> 1] = Exp2Pair<T>::run(s[i], s[i + 1], csc, mc, ps0, ps1);
         l_run = l_run * alpha + (ps0 + ps1);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            pf[0][j] = Elem<T>::pack2(s[2 * j], s[2 * j + 1]);
-            pf[1][j] = Elem<T>::pack2(s[8 + 2 * j], s[8 + 2 * j + 1]);
-        }
     };
     // wave-uniform: would softmax of this block move some row's running max by more than THR?
     auto max_would_move = [&](const f32x16 &s, float m_run) -> bool {
@@ -458,21 +483,11 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     auto softmax_keep_max = [&](f32x16 &s, u32x4 (&pf)[2], float m_run, float &l_run) {
         const float mc = (m_run == -INFINITY ? 0.f : m_run) * p.scale_log2;
         float ps0 = 0.f, ps1 = 0.f;
+        const float csc = p.scale_log2;  // kernarg: wave-uniform, lives in an SGPR
 #pragma unroll
-        for (int i = 0; i < 16; i += 2) {
-            const float a = __builtin_amdgcn_exp2f(s[i] * p.scale_log2 - mc);
-            const float b = __builtin_amdgcn_exp2f(s[i + 1] * p.scale_log2 - mc);
-            s[i] = a;
-            s[i + 1] = b;
-            ps0 = add_f32(ps0, a);
-            ps1 = add_f32(ps1, b);
-        }
+        for (int i = 0; i < 16; i += 2)
+            pf[i >> 3][(i & 7) >> 1] = Exp2Pair<T>::run(s[i], s[i + 1], csc, mc, ps0, ps1);
         l_run += ps0 + ps1;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            pf[0][j] = Elem<T>::pack2(s[2 * j], s[2 * j + 1]);
-            pf[1][j] = Elem<T>::pack2(s[8 + 2 * j], s[8 + 2 * j + 1]);
-        }
     };
     // Rare path (a running max grew by more than THR).  O lives in AGPRs and is written by asm MFMAs whose
     // result hazard hipcc does not pad: drain the matrix pipe, with the accumulators as operands of the
@@ -571,7 +586,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
             }
             return vf;
         };
-        const float csc = p.scale_log2;
+        const float csc = p.scale_log2;  // kernarg: wave-uniform, lives in an SGPR
 
         // ---------- phase 1: S(j+1) = K.Q^T on the matrix pipe || exp/sum/pack of B(j) on the VALU ----------
         // LDS fragments are fetched two slices (>= 128 cycles) ahead of the MFMA that consumes them; the first
@@ -596,13 +611,8 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
                     Mfma<T>::s_acc(sb_nxt, kf0, qb[ks]);
                 }
 #pragma unroll
-                for (int e = ks * PER; e < (ks + 1) * PER && !(FA_ABLATE & 1); e += 2) {
-                    const float x = __builtin_amdgcn_exp2f(sb_cur[e] * csc - mcb);
-                    const float y = __builtin_amdgcn_exp2f(sb_cur[e + 1] * csc - mcb);
-                    ps0 = add_f32(ps0, x);
-                    ps1 = add_f32(ps1, y);
-                    pb[e >> 3][(e & 7) >> 1] = Elem<T>::pack2(x, y);
-                }
+                for (int e = ks * PER; e < (ks + 1) * PER && !(FA_ABLATE & 1); e += 2)
+                    pb[e >> 3][(e & 7) >> 1] = Exp2Pair<T>::run(sb_cur[e], sb_cur[e + 1], csc, mcb, ps0, ps1);
                 kf0 = kf1;
                 kf1 = kf2;
                 __builtin_amdgcn_sched_barrier(0);
@@ -618,13 +628,8 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
             float mxa = 0.f, mxb = 0.f, nxa = 0.f, nxb = 0.f, mca = 0.f, ps0 = 0.f, ps1 = 0.f, m_new_b = 0.f;
             auto exp_a = [&](int e0, int e1) {  // elements [e0, e1) of A, e0 even
 #pragma unroll
-                for (int e = e0; e < e1; e += 2) {
-                    const float x = __builtin_amdgcn_exp2f(sa[e] * csc - mca);
-                    const float y = __builtin_amdgcn_exp2f(sa[e + 1] * csc - mca);
-                    ps0 = add_f32(ps0, x);
-                    ps1 = add_f32(ps1, y);
-                    pa_nxt[e >> 3][(e & 7) >> 1] = Elem<T>::pack2(x, y);
-                }
+                for (int e = e0; e < e1; e += 2)
+                    pa_nxt[e >> 3][(e & 7) >> 1] = Exp2Pair<T>::run(sa[e], sa[e + 1], csc, mca, ps0, ps1);
             };
             auto chunk = [&](int c) {
                 if (c == 0) {  // row max of A(j+1)

@@ -22,10 +22,14 @@ def regs(tok):
     return set()
 
 
+TRANS = ('v_exp_', 'v_log_', 'v_rcp_', 'v_rsq_', 'v_sqrt_', 'v_sin_', 'v_cos_')
+
+
 def scan(path, required=REQUIRED):
     violations = []
     kernel = None
     window = []  # (states_so_far_after, dst_regs, text, lineno) of recent VALU writes
+    last_trans = None  # (dst_regs, text, lineno) when the previous instruction was a transcendental
     for lineno, raw in enumerate(open(path), 1):
         l = raw.strip()
         m = re.match(r'^(_Z\w+):', l)
@@ -36,6 +40,22 @@ def scan(path, required=REQUIRED):
         if not l or l.startswith(';') or l.startswith('.') or l.endswith(':'):
             continue
         op = l.split()[0]
+        # gfx940+ trans forwarding: a non-transcendental VALU may not read a transcendental's result in the very
+        # next instruction (1 wait state); hipcc pads this only for instructions it scheduled itself
+        if last_trans is not None and op.startswith('v_') and not op.startswith(TRANS):
+            srcs_t = set()
+            parts = l.split(None, 1)[1].split(',') if ' ' in l else []
+            for t in parts[1:]:
+                srcs_t |= regs(t.strip().lstrip('-').lstrip('|').rstrip('|'))
+            if op.startswith('v_mfma') or op.startswith('v_cmp'):
+                for t in parts[:1]:
+                    pass
+            if srcs_t & last_trans[0]:
+                violations.append((kernel, last_trans[2], last_trans[1], lineno, l, 0))
+        if op.startswith(TRANS):
+            last_trans = (regs(l.split(None, 1)[1].split(',')[0]), l, lineno)
+        elif op not in ('s_waitcnt',):
+            last_trans = None
         if op.startswith('v_mfma'):
             ops = l.split(None, 1)[1].split(',')
             srcs = set()
