@@ -50,6 +50,21 @@ def algorithmic_bytes(w):
     return 2 * (2 * rows * h * d + 2 * rows * hk * d) + 4 * rows * h  # Q+O, K+V (bf16) + LSE (fp32)
 
 
+def measured_traffic(workload_key):
+    """HBM bytes per launch from the committed rocprofv3 PMC summary (profiles/rNN_traffic.json), newest round that
+    measured this workload; None when no counter pass has been committed for it."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json"))):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        if d.get("workload") == workload_key:
+            best = d.get("hbm_bytes_per_launch")
+    return best
+
+
 def make_inputs(w, device, seed):
     import torch
     _, b, h, hk, s, d, causal, lens = w
@@ -194,7 +209,7 @@ def main():
                        "head_dim": w[5], "causal": w[6], "sharding": f"batch shard x{world}, no collective"},
             "roofline": {
                 "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": measured_traffic(args.workload),
                 "kernel_ms_avg": round(avg_kernel_ms, 4), "kernel_ms_median": round(kernel_ms[len(kernel_ms) // 2], 4),
                 "kernel_ms_min": round(kernel_ms[0], 4), "algorithmic_flops_per_launch": flops,
                 "algorithmic_bytes_per_launch": algorithmic_bytes(w),

@@ -1,0 +1,88 @@
+"""CPU tests of the drop-in boundary: the C-ABI library builds for gfx950 (cross-compiled, no GPU), loads, exports
+every symbol include/fa_fwd.h declares, and rejects bad parameters with the documented status codes.  No kernel is
+launched here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from flash_attention_annotated_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    text = open(os.path.join(ROOT, "include", "fa_fwd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(fa_\w+)\s*\(", text)))
+
+
+def test_header_symbols_all_exported(built_lib):
+    names = _header_functions()
+    assert set(names) == set(_lib.EXPORTED_SYMBOLS), "binding list and header disagree"
+    for n in names:
+        assert hasattr(built_lib, n), f"{n} declared in include/fa_fwd.h but not exported"
+
+
+def test_struct_layout_and_version(built_lib):
+    assert built_lib.fa_fwd_params_size() == ctypes.sizeof(_lib.FaFwdParams)
+    assert built_lib.fa_abi_version() == _lib.FA_ABI_VERSION
+
+
+def _good():
+    p = _lib.new_params()
+    for f in ("q", "k", "v", "o", "softmax_lse"):
+        setattr(p, f, 0x10000)
+    p.b, p.seqlen_q, p.seqlen_k, p.h, p.h_k, p.d = 2, 128, 128, 4, 2, 64
+    p.dtype = _lib.FA_DTYPE_BF16
+    for t in ("q", "k", "v", "o"):
+        setattr(p, f"{t}_row_stride", 4 * 64)
+        setattr(p, f"{t}_head_stride", 64)
+        setattr(p, f"{t}_batch_stride", 128 * 4 * 64)
+    p.k_row_stride = p.v_row_stride = 2 * 64
+    p.softmax_scale = 0.125
+    p.window_size_left = p.window_size_right = -1
+    return p
+
+
+def test_validate_accepts_good_params(built_lib):
+    assert built_lib.fa_fwd_validate(ctypes.byref(_good())) == 0
+    assert built_lib.fa_strerror(0) == b"ok"
+
+
+@pytest.mark.parametrize("mutate,code", [
+    (lambda p: setattr(p, "dtype", 7), -2),                 # FA_ERR_BAD_DTYPE
+    (lambda p: setattr(p, "d", 264), -3),                   # head dim > 256
+    (lambda p: setattr(p, "d", 60), -3),                    # head dim % 8
+    (lambda p: setattr(p, "h_k", 3), -4),                   # h % h_k
+    (lambda p: setattr(p, "b", 0), -5),                     # batch size must be positive
+    (lambda p: setattr(p, "q", 0), -1),                     # NULL tensor
+    (lambda p: setattr(p, "q_row_stride", 250), -6),        # rows not 16-byte aligned
+    (lambda p: setattr(p, "k", 0x10008), -6),               # base not 16-byte aligned
+    (lambda p: setattr(p, "abi_version", 99), -9),          # FA_ERR_BAD_ABI
+    (lambda p: setattr(p, "struct_size", 8), -9),
+])
+def test_validate_rejects(built_lib, mutate, code):
+    p = _good()
+    mutate(p)
+    st = built_lib.fa_fwd_validate(ctypes.byref(p))
+    assert st == code
+    assert len(built_lib.fa_strerror(st)) > 0
+    # fa_fwd runs the same validation before touching the device: same code, nothing launched
+    assert built_lib.fa_fwd(ctypes.byref(p), None) == code
+
+
+def test_error_texts_are_the_reference_messages(built_lib):
+    assert b"only support fp16 and bf16" in built_lib.fa_strerror(-2)      # csrc/flash_attn/flash_api.cpp:373
+    assert b"at most 256" in built_lib.fa_strerror(-3)                     # :391
+    assert b"must divide number of heads in query" in built_lib.fa_strerror(-4)  # :393
+
+
+def test_tile_shape(built_lib):
+    bm, bn = ctypes.c_int32(), ctypes.c_int32()
+    assert built_lib.fa_fwd_tile_shape(128, _lib.FA_DTYPE_BF16, 0, ctypes.byref(bm), ctypes.byref(bn)) == 0
+    assert (bm.value, bn.value) == (256, 64)
+    assert built_lib.fa_fwd_tile_shape(256, _lib.FA_DTYPE_BF16, 1, ctypes.byref(bm), ctypes.byref(bn)) == 0
+    assert (bm.value, bn.value) == (128, 64)
+    assert built_lib.fa_fwd_tile_shape(300, 0, 0, None, None) == -3

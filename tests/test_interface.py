@@ -1,0 +1,73 @@
+"""CPU tests of the Python host layer: it mirrors the reference's operator interface (names, argument order,
+defaults) and it never computes attention on a fallback path."""
+import inspect
+
+import pytest
+import torch
+
+import flash_attention_annotated_amd as fa
+from flash_attention_annotated_amd import bert_padding, flash_attn_2_cuda, sharding
+
+
+def _params(f):
+    return [(n, p.default) for n, p in inspect.signature(f).parameters.items()]
+
+
+def test_flash_attn_func_signature():
+    """flash_attn/flash_attn_interface.py:1145-1157"""
+    assert _params(fa.flash_attn_func) == [
+        ("q", inspect._empty), ("k", inspect._empty), ("v", inspect._empty), ("dropout_p", 0.0),
+        ("softmax_scale", None), ("causal", False), ("window_size", (-1, -1)), ("softcap", 0.0),
+        ("alibi_slopes", None), ("deterministic", False), ("return_attn_probs", False)]
+
+
+def test_flash_attn_varlen_func_signature():
+    """flash_attn/flash_attn_interface.py:1380-1397"""
+    assert _params(fa.flash_attn_varlen_func) == [
+        ("q", inspect._empty), ("k", inspect._empty), ("v", inspect._empty), ("cu_seqlens_q", inspect._empty),
+        ("cu_seqlens_k", inspect._empty), ("max_seqlen_q", inspect._empty), ("max_seqlen_k", inspect._empty),
+        ("dropout_p", 0.0), ("softmax_scale", None), ("causal", False), ("window_size", (-1, -1)), ("softcap", 0.0),
+        ("alibi_slopes", None), ("deterministic", False), ("return_attn_probs", False), ("block_table", None)]
+
+
+def test_extension_module_surface():
+    """The five entry points flash_attn_interface.py looks up on flash_attn_2_cuda (:91,:168,:269,:369,:1594),
+    with the positional arity of the pybind signatures (csrc/flash_attn/flash_api.cpp:350-363, 514-535)."""
+    for name in ("fwd", "varlen_fwd", "bwd", "varlen_bwd", "fwd_kvcache"):
+        assert callable(getattr(flash_attn_2_cuda, name))
+    assert len(inspect.signature(flash_attn_2_cuda.fwd).parameters) == 13
+    assert len(inspect.signature(flash_attn_2_cuda.varlen_fwd).parameters) == 21
+    import flash_attn_2_cuda as top_level_alias  # the name the reference imports
+    assert top_level_alias.fwd is flash_attn_2_cuda.fwd
+    for f in (flash_attn_2_cuda.bwd, flash_attn_2_cuda.varlen_bwd, flash_attn_2_cuda.fwd_kvcache):
+        with pytest.raises(RuntimeError, match="not built"):
+            f()
+
+
+def test_no_cpu_fallback():
+    """CPU tensors are rejected like the reference's CHECK_DEVICE does; nothing is computed off the GPU."""
+    q = torch.randn(1, 16, 2, 64, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="must be on CUDA"):
+        fa.flash_attn_func(q, q, q)
+    with pytest.raises(RuntimeError, match="only support fp16 and bf16"):
+        fa.flash_attn_func(q.float(), q.float(), q.float())
+
+
+def test_unpad_pad_roundtrip():
+    torch.manual_seed(0)
+    x = torch.randn(3, 7, 2, 4)
+    mask = torch.tensor([[1, 1, 1, 0, 0, 0, 0], [1, 1, 1, 1, 1, 1, 1], [1, 0, 0, 0, 0, 0, 0]], dtype=torch.bool)
+    xu, idx, cu, mx, used = bert_padding.unpad_input(x, mask)
+    assert cu.tolist() == [0, 3, 10, 11] and cu.dtype == torch.int32 and mx == 7 and used.tolist() == [3, 7, 1]
+    back = bert_padding.pad_input(xu, idx, 3, 7)
+    assert torch.equal(back[mask], x[mask]) and torch.all(back[~mask] == 0)
+
+
+def test_shard_range_partitions():
+    for n in (1, 4, 7, 32):
+        for world in (1, 2, 3, 8):
+            spans = [sharding.shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1

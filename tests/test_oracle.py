@@ -1,0 +1,112 @@
+"""CPU tests of the oracle (test infrastructure): replay of the reference's frozen outputs, cross-check of the
+torch restatement against the independent C fp64 restatement, and the mask diagrams of the reference docstring."""
+import ctypes
+import os
+import subprocess
+
+import pytest
+import torch
+
+from oracle import attention_ref as oracle
+from oracle.cases import CASES, checksum, make_inputs, padding_masks
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_oracle_reproduces_reference_golden(name, golden):
+    """tests/golden/attention_ref_golden.pt holds the outputs of the reference's own attention_ref
+    (tests/test_util.py:185-274) for these seeded inputs; the restatement must reproduce them."""
+    c, g = CASES[name], golden[name]
+    q, k, v = make_inputs(c)
+    for t, want in zip((q, k, v), g["input_checksum"].tolist()):
+        assert abs(checksum(t) - want) <= 1e-6 * max(1.0, abs(want)), "seeded inputs differ from the frozen ones"
+    qm, km = padding_masks(c)
+    kw = dict(causal=c["causal"], window_size=tuple(c["window"]), softcap=c["softcap"])
+    st = c["store_row_stride"]
+    out32, _ = oracle.attention_ref(q.float(), k.float(), v.float(), qm, km, **kw)
+    out_pt, _ = oracle.attention_ref(q, k, v, qm, km, **kw, upcast=False, reorder_ops=True)
+    # fp32 math: same op order as the reference -> agreement to rounding (bit-identical in the build container)
+    assert (out32[:, ::st] - g["out_ref_fp32"]).abs().max().item() <= 2e-6
+    tol_pt = 0.0 if q.dtype == torch.float32 else 2e-2  # low-precision path: allow one ulp-level flip across hosts
+    assert (out_pt[:, ::st].float() - g["out_pt"].float()).abs().max().item() <= tol_pt + 1e-6
+    _, _, lse = oracle.attention_ref(q, k, v, qm, km, **kw, return_lse=True)
+    fin = torch.isfinite(g["lse"])
+    assert torch.equal(torch.isfinite(lse[:, :, ::st]), fin)
+    if fin.any():
+        assert (lse[:, :, ::st][fin] - g["lse"][fin]).abs().max().item() <= 1e-5
+
+
+def _c_oracle():
+    so = os.path.join(ROOT, "oracle", "_ref", "liboracle_attn.so")
+    if not os.path.exists(so):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True)
+    lib = ctypes.CDLL(so)
+    f = lib.fa_oracle_attention_f32
+    f.restype = ctypes.c_int
+    f.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] * 6 + [ctypes.c_float] + [ctypes.c_int] * 3 + [ctypes.c_float]
+    return f
+
+
+@pytest.mark.parametrize("causal,window,softcap,sq,sk,h,hk,d", [
+    (False, (-1, -1), 0.0, 64, 64, 2, 2, 32),
+    (True, (-1, -1), 0.0, 37, 91, 4, 2, 64),
+    (True, (-1, -1), 0.0, 91, 37, 4, 1, 64),
+    (False, (7, 3), 0.0, 50, 70, 2, 2, 16),
+    (False, (0, 0), 0.0, 33, 33, 1, 1, 8),
+    (False, (-1, -1), 15.0, 40, 48, 2, 1, 32),
+])
+def test_c_oracle_agrees_with_torch_oracle(causal, window, softcap, sq, sk, h, hk, d):
+    """Two independent restatements (torch fp32, plain C fp64) of the same definition agree."""
+    f = _c_oracle()
+    torch.manual_seed(sq * 1000 + sk)
+    q = torch.randn(2, sq, h, d) * (4.0 if softcap else 1.0)
+    k = torch.randn(2, sk, hk, d)
+    v = torch.randn(2, sk, hk, d)
+    out = torch.empty_like(q)
+    lse = torch.empty(2, h, sq)
+    st = f(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(), 2, sq, sk, h, hk, d,
+           d ** -0.5, int(causal), window[0], window[1], softcap)
+    assert st == 0
+    ref, _, lse_ref = oracle.attention_ref(q, k, v, causal=causal, window_size=window, softcap=softcap, return_lse=True)
+    assert (out - ref).abs().max().item() <= 1e-5
+    fin = torch.isfinite(lse_ref)
+    assert torch.equal(torch.isfinite(lse), fin)
+    assert (lse[fin] - lse_ref[fin]).abs().max().item() <= 2e-5
+
+
+def test_docstring_causal_masks():
+    """flash_attn/flash_attn_interface.py:1164-1174: causal masks are aligned to the bottom-right corner;
+    (sq, sk) = (2, 5) keeps [[1,1,1,1,0],[1,1,1,1,1]]; (5, 2) keeps [[0,0],[0,0],[0,0],[1,0],[1,1]]."""
+    m = ~oracle.local_mask(2, 5, (-1, 0))
+    assert m.int().tolist() == [[1, 1, 1, 1, 0], [1, 1, 1, 1, 1]]
+    m = ~oracle.local_mask(5, 2, (-1, 0))
+    assert m.int().tolist() == [[0, 0], [0, 0], [0, 0], [1, 0], [1, 1]]
+    q = torch.randn(1, 5, 1, 8)
+    k = torch.randn(1, 2, 1, 8)
+    v = torch.randn(1, 2, 1, 8)
+    out, attn, lse = oracle.attention_ref(q, k, v, causal=True, return_lse=True)
+    assert torch.all(out[0, :3] == 0), "rows with no visible key produce zeros"
+    assert torch.all(torch.isposinf(lse[0, 0, :3]))
+    assert torch.allclose(out[0, 3, 0], v[0, 0, 0], atol=1e-6)
+
+
+def test_varlen_oracle_matches_padded_oracle():
+    torch.manual_seed(0)
+    b, sq, sk, h, hk, d = 3, 17, 29, 4, 2, 16
+    q = torch.randn(b, sq, h, d)
+    k = torch.randn(b, sk, hk, d)
+    v = torch.randn(b, sk, hk, d)
+    lens_q, lens_k = [17, 5, 11], [29, 13, 1]
+    qm = torch.arange(sq).view(1, -1) < torch.tensor(lens_q).view(-1, 1)
+    km = torch.arange(sk).view(1, -1) < torch.tensor(lens_k).view(-1, 1)
+    ref, _ = oracle.attention_ref(q, k, v, qm, km, causal=True)
+    cq = torch.tensor([0, 17, 22, 33], dtype=torch.int32)
+    ck = torch.tensor([0, 29, 42, 43], dtype=torch.int32)
+    qu = torch.cat([q[i, :lens_q[i]] for i in range(b)])
+    ku = torch.cat([k[i, :lens_k[i]] for i in range(b)])
+    vu = torch.cat([v[i, :lens_k[i]] for i in range(b)])
+    out_u, lse_u = oracle.attention_varlen_ref(qu, ku, vu, cq, ck, causal=True)
+    for i in range(b):
+        assert (out_u[cq[i]:cq[i + 1]] - ref[i, :lens_q[i]]).abs().max().item() <= 1e-6
+    assert lse_u.shape == (h, 33)
