@@ -188,6 +188,11 @@ int fa_fwd(const fa_fwd_params *p, void *stream_) {
     if (wl >= p->seqlen_k) wl = -1;
     if (wr >= p->seqlen_k) wr = -1;
     if (p->is_causal) wr = 0;
+    // set_params_fprop csrc/flash_attn/flash_api.cpp:141-142: a one-sided window gets seqlen_k on the other side.
+    // For a left-only window that is NOT the same as unbounded when seqlen_q > seqlen_k (the bottom-right aligned
+    // diagonal starts left of key 0), so it is mirrored.  The symmetric rule (right-only -> left = seqlen_k) never
+    // masks anything (row + sk - sq - seqlen_k < 0 for every row) and is left as "unbounded".
+    if (wl >= 0 && wr < 0) wr = p->seqlen_k;
     kp.window_left = wl;
     kp.window_right = wr;
 

@@ -30,7 +30,7 @@ namespace fa {
 // log2-domain growth of the running max below which O/l are NOT rescaled (the stale max is kept and P may
 // reach 2^THR).  0 = rescale whenever any row's max moves: bit-identical to always rescaling.
 #ifndef FA_RESCALE_THR
-#define FA_RESCALE_THR 8
+#define FA_RESCALE_THR 8  /* must be > 0: the fast path keeps a stale max and guards it with 2^THR */
 #endif
 
 
@@ -76,8 +76,10 @@ template <> struct Exp2Pair<_Float16> {
     }
 };
 
-// MFMA wrappers with explicit register classes: S accumulators and Q in arch VGPRs, the O accumulators in AGPRs
-// (only the matrix pipe touches them in the fast loop).
+// MFMA wrappers with explicit register classes: S accumulators in arch VGPRs (the VALU reads them), Q (B operand
+// of the score product) and the O accumulators in AGPRs.  Q is an in/out ("+a") operand of every score MFMA
+// although it is only read: each statement then hands the NEXT one an AGPR-defined value, which keeps hipcc's
+// register allocator from parking Q in VGPRs and copying it into AGPRs in front of every MFMA (unpadded copies).
 // hipcc does not pad hazards of asm MFMAs: callers keep >= 1 independent MFMA (or a drain) between an asm
 // MFMA and any VALU reader of its result.
 // Row max of a 32x32 score block over this lane's 16 registers, seeded with m: two v_max3 chains in ONE asm
@@ -100,11 +102,11 @@ template <typename T> struct Mfma;
 template <> struct Mfma<__bf16> {
     // PAD variants (generic path): hipcc may put its own VALU / v_accvgpr writes of an operand right in front of
     // an asm MFMA and pads nothing for asm, so the padded forms carry the 2 wait states themselves.
-    static __device__ __forceinline__ void s_first_pad(f32x16 &d, u32x4 k, u32x4 q) {
-        asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(k), "a"(q));
+    static __device__ __forceinline__ void s_first_pad(f32x16 &d, u32x4 k, u32x4 &q) {
+        asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %2, %1, 0" : "=&v"(d), "+a"(q) : "v"(k));
     }
-    static __device__ __forceinline__ void s_acc_pad(f32x16 &d, u32x4 k, u32x4 q) {
-        asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(k), "a"(q));
+    static __device__ __forceinline__ void s_acc_pad(f32x16 &d, u32x4 k, u32x4 &q) {
+        asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %2, %1, %0" : "+v"(d), "+a"(q) : "v"(k));
     }
     static __device__ __forceinline__ void o_acc_pad(f32x16 &o, u32x4 v, u32x4 pf) {
         asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(o) : "v"(v), "v"(pf));
@@ -112,11 +114,11 @@ template <> struct Mfma<__bf16> {
     static __device__ __forceinline__ void o_zero(f32x16 &o, u32x4 z) {  // O = 0*0 + 0: no VALU/accvgpr write involved
         asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %1, 0" : "=a"(o) : "v"(z));
     }
-    static __device__ __forceinline__ void s_first(f32x16 &d, u32x4 k, u32x4 q) {
-        asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(k), "a"(q));
+    static __device__ __forceinline__ void s_first(f32x16 &d, u32x4 k, u32x4 &q) {
+        asm("v_mfma_f32_32x32x16_bf16 %0, %2, %1, 0" : "=&v"(d), "+a"(q) : "v"(k));
     }
-    static __device__ __forceinline__ void s_acc(f32x16 &d, u32x4 k, u32x4 q) {
-        asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(k), "a"(q));
+    static __device__ __forceinline__ void s_acc(f32x16 &d, u32x4 k, u32x4 &q) {
+        asm("v_mfma_f32_32x32x16_bf16 %0, %2, %1, %0" : "+v"(d), "+a"(q) : "v"(k));
     }
     static __device__ __forceinline__ void o_acc(f32x16 &o, u32x4 v, u32x4 pf) {
         asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(o) : "v"(v), "v"(pf));
@@ -129,11 +131,11 @@ template <> struct Mfma<__bf16> {
     }
 };
 template <> struct Mfma<_Float16> {
-    static __device__ __forceinline__ void s_first_pad(f32x16 &d, u32x4 k, u32x4 q) {
-        asm("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(d) : "v"(k), "a"(q));
+    static __device__ __forceinline__ void s_first_pad(f32x16 &d, u32x4 k, u32x4 &q) {
+        asm("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %2, %1, 0" : "=&v"(d), "+a"(q) : "v"(k));
     }
-    static __device__ __forceinline__ void s_acc_pad(f32x16 &d, u32x4 k, u32x4 q) {
-        asm("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "v"(k), "a"(q));
+    static __device__ __forceinline__ void s_acc_pad(f32x16 &d, u32x4 k, u32x4 &q) {
+        asm("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %2, %1, %0" : "+v"(d), "+a"(q) : "v"(k));
     }
     static __device__ __forceinline__ void o_acc_pad(f32x16 &o, u32x4 v, u32x4 pf) {
         asm("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(o) : "v"(v), "v"(pf));
@@ -141,11 +143,11 @@ template <> struct Mfma<_Float16> {
     static __device__ __forceinline__ void o_zero(f32x16 &o, u32x4 z) {
         asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %1, 0" : "=a"(o) : "v"(z));
     }
-    static __device__ __forceinline__ void s_first(f32x16 &d, u32x4 k, u32x4 q) {
-        asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(d) : "v"(k), "a"(q));
+    static __device__ __forceinline__ void s_first(f32x16 &d, u32x4 k, u32x4 &q) {
+        asm("v_mfma_f32_32x32x16_f16 %0, %2, %1, 0" : "=&v"(d), "+a"(q) : "v"(k));
     }
-    static __device__ __forceinline__ void s_acc(f32x16 &d, u32x4 k, u32x4 q) {
-        asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "v"(k), "a"(q));
+    static __device__ __forceinline__ void s_acc(f32x16 &d, u32x4 k, u32x4 &q) {
+        asm("v_mfma_f32_32x32x16_f16 %0, %2, %1, %0" : "+v"(d), "+a"(q) : "v"(k));
     }
     static __device__ __forceinline__ void o_acc(f32x16 &o, u32x4 v, u32x4 pf) {
         asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(o) : "v"(v), "v"(pf));
@@ -472,23 +474,6 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
             pf[i >> 3][(i & 7) >> 1] = Exp2Pair<T>::run(s[i], s[i + 1], csc, mc, ps0, ps1);
         l_run = l_run * alpha + (ps0 + ps1);
     };
-    // wave-uniform: would softmax of this block move some row's running max by more than THR?
-    auto max_would_move = [&](const f32x16 &s, float m_run) -> bool {
-        float mxa, mxb;
-        rowmax16(s, m_run, mxa, mxb);
-        const float m_new = half_swap_max(fmaxf(mxa, mxb));
-        return __any((m_new - m_run) * p.scale_log2 > THR);
-    };
-    // exp/sum/pack with the running max left where it is (caller has checked max_would_move == false)
-    auto softmax_keep_max = [&](f32x16 &s, u32x4 (&pf)[2], float m_run, float &l_run) {
-        const float mc = (m_run == -INFINITY ? 0.f : m_run) * p.scale_log2;
-        float ps0 = 0.f, ps1 = 0.f;
-        const float csc = p.scale_log2;  // kernarg: wave-uniform, lives in an SGPR
-#pragma unroll
-        for (int i = 0; i < 16; i += 2)
-            pf[i >> 3][(i & 7) >> 1] = Exp2Pair<T>::run(s[i], s[i + 1], csc, mc, ps0, ps1);
-        l_run += ps0 + ps1;
-    };
     // Rare path (a running max grew by more than THR).  O lives in AGPRs and is written by asm MFMAs whose
     // result hazard hipcc does not pad: drain the matrix pipe, with the accumulators as operands of the
     // drain so no reader can be scheduled above it.
@@ -533,14 +518,22 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     __syncthreads();  // every wave has read K tile n_min before tile n_min's end overwrites its buffer
 
     const int J = 2 * (n_max - n_min);
-    // ---- generic half-step: any boundary case (masks, last half-steps of the wave, rescales) --------------
+    // ---- generic half-step: any boundary case (masks, last half-steps of the wave, rescales, redo after the fast
+    //      path tripped its overflow guard). ---------------------------------------------------------------------
+    bool redo_a = false;      // P_A(j) / l_a were produced with a stale max that turned out too small: redo from sa
+    float l_a_saved = 0.f;
     auto generic_half = [&](int j) {
         const int i = j >> 1, kb = j & 1, slot = i & 1, n = n_min + i;
-        if (kb == 0) {  // K tile n+2 over K tile n, V tile n+1 over V tile n-1 (both last read during tile n-1)
+        if (kb == 0) {  // K tile n+2 over K tile n, V tile n+1 over V tile n-1 (last read in tile n-1)
             if (n + 2 <= n_max) load_k(n + 2, slot);
             if (n + 1 < n_max) load_v(n + 1, slot ^ 1);
         }
         if (j < jend) {
+            if (redo_a) {  // sa still holds S_A(j)
+                l_a = l_a_saved;
+                softmax(sa, pax, m_a, l_a, alpha_a, moved_a);
+                redo_a = false;
+            }
             if (moved_a) rescale(oa, alpha_a);  // deferred from softmax A(j)
             moved_a = false;
             if (j + 1 < jend) {
@@ -562,11 +555,16 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
         }
         if (kb == 1) tile_barrier();  // this tile's LDS-DMA has landed; every wave is done with the old buffers
     };
-    // ---- fast half-step: interior of the sweep.  No masks, a next half-step exists, and no running max
-    //      moves (checked one half-step ahead), so O is touched by nothing but the AGPR-pinned MFMAs.
+    // ---- fast half-step: interior of the sweep (no masks, a next half-step exists).  The running max is NOT
+    //      recomputed here: P = exp2(S*c - m_stale*c) and the per-lane partial row sums, which are needed anyway,
+    //      double as the guard -- a partial sum above 2^THR means some score outgrew the stale max by up to THR
+    //      (or more) and the block is redone by the generic path with a fresh max.  So O is touched by nothing but
+    //      the AGPR-pinned MFMAs, and the VALU work per 32x32 block is fma+exp+add per score plus one cvt_pk per pair.
     //      Hand-placed schedule: the wave is alone on its SIMD and issues in order, so every pair of MFMAs is
-    //      followed by a fixed slice of the softmax VALU work (one v_exp per MFMA gap) and the slices are pinned
-    //      with sched_barrier.  Returns true when the NEXT half-step needs the generic path. ------------------
+    //      followed by a fixed slice of that work and the slices are pinned with sched_barrier.
+    //      (B's P is consumed in the same half-step, so B keeps a cheap max look-ahead in phase 2 instead of the sum
+    //      guard.)  Returns true when the NEXT half-step must take the generic path; redo_a says A must be redone. --
+    constexpr float LIM = (THR > 0.f) ? (float)(1u << (int)THR) : 1.0f;
     auto fast_half = [&](auto slot_c, auto kb_c, f32x16 &sb_cur, f32x16 &sb_nxt, u32x4 (&pa_cur)[2],
                          u32x4 (&pa_nxt)[2]) -> bool {
         constexpr int SLOT = decltype(slot_c)::value, KB = decltype(kb_c)::value;
@@ -620,43 +618,12 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
             l_b += ps0 + ps1;
         }
 
-        // ---------- phase 2: O += V^T.P^T on the matrix pipe || softmax of A(j+1) + max look-ahead of B(j+1) ----
-        bool b_moves;
+        // ---------- phase 2: O += V^T.P^T on the matrix pipe || exp/sum/pack of A(j+1) on the VALU ----------
         {
-            constexpr int NSTEP = 2 * DBLOCKS;      // (db, st) steps, two MFMAs each
-            constexpr int CPS = 8 / NSTEP;          // VALU chunks per step (8 chunks in all)
-            float mxa = 0.f, mxb = 0.f, nxa = 0.f, nxb = 0.f, mca = 0.f, ps0 = 0.f, ps1 = 0.f, m_new_b = 0.f;
-            auto exp_a = [&](int e0, int e1) {  // elements [e0, e1) of A, e0 even
-#pragma unroll
-                for (int e = e0; e < e1; e += 2)
-                    pa_nxt[e >> 3][(e & 7) >> 1] = Exp2Pair<T>::run(sa[e], sa[e + 1], csc, mca, ps0, ps1);
-            };
-            auto chunk = [&](int c) {
-                if (c == 0) {  // row max of A(j+1)
-                    rowmax16(sa, m_a, mxa, mxb);
-                } else if (c == 1) {  // decide, rescale factors
-                    const float m_new = half_swap_max(fmaxf(mxa, mxb));
-                    moved_a = __any((m_new - m_a) * csc > THR);
-                    const float m_eff = moved_a ? m_new : m_a;
-                    mca = (m_eff == -INFINITY ? 0.f : m_eff) * csc;
-                    alpha_a = __builtin_amdgcn_exp2f(m_a * csc - mca);
-                    m_a = m_eff;
-                } else if (c == 2) {
-                    exp_a(0, 2);
-                    rowmax16(sb_nxt, m_b, nxa, nxb);
-                } else if (c == 3) {
-                    exp_a(2, 6);
-                } else if (c == 4) {
-                    exp_a(6, 10);
-                    m_new_b = half_swap_max(fmaxf(nxa, nxb));
-                } else if (c == 5) {
-                    exp_a(10, 12);
-                } else if (c == 6) {
-                    exp_a(12, 14);
-                } else {
-                    exp_a(14, 16);
-                }
-            };
+            constexpr int NSTEP = 2 * DBLOCKS;  // (db, st) steps, two MFMAs each
+            constexpr int PER = 16 / NSTEP;     // score elements of A(j+1) finished per step
+            const float mca = (m_a == -INFINITY ? 0.f : m_a) * csc;
+            float ps0 = 0.f, ps1 = 0.f, nxa = 0.f, nxb = 0.f;
             u32x4 vf = vfa, vf_next = vfb;
 #pragma unroll
             for (int t = 0; t < NSTEP; ++t) {
@@ -667,15 +634,23 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
                 else Mfma<T>::o_acc(oa[db], vf, pa_cur[st]);
                 Mfma<T>::o_acc(ob[db], vf, pb[st]);
 #pragma unroll
-                for (int c = t * CPS; c < (t + 1) * CPS && !(FA_ABLATE & 2); ++c) chunk(c);
+                for (int e = t * PER; e < (t + 1) * PER && !(FA_ABLATE & 2); e += 2)
+                    pa_nxt[e >> 3][(e & 7) >> 1] = Exp2Pair<T>::run(sa[e], sa[e + 1], csc, mca, ps0, ps1);
+                if (t == NSTEP / 2 && !(FA_ABLATE & 2)) rowmax16(sb_nxt, m_b, nxa, nxb);  // look-ahead max of B(j+1)
                 vf = vf_next;
                 vf_next = vf_next2;
                 __builtin_amdgcn_sched_barrier(0);
             }
-            l_a = l_a * alpha_a + (ps0 + ps1);
-            b_moves = __any((m_new_b - m_b) * csc > THR);
+            const float ps = ps0 + ps1;
+            l_a_saved = l_a;
+            l_a += ps;
+            redo_a = __any(!(ps <= LIM));  // also catches inf / NaN
+            float nb;
+            asm("v_max_f32 %0, %1, %2" : "=v"(nb) : "v"(nxa), "v"(nxb));
+            const float m_new_b = half_swap_max(nb);
+            const bool b_moves = __any((m_new_b - m_b) * csc > THR);
+            return redo_a || b_moves;
         }
-        return moved_a || b_moves;
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
@@ -693,6 +668,12 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     }
     fast_last = __builtin_amdgcn_readfirstlane(fast_last);
 
+    // Driver.  ONE call site of generic_half (its body is large; inlining it twice wrecks register allocation).
+    auto to_canonical_after_odd = [&]() {  // after a KB = 0 fast half-step the next scores / P_A live in sby / pay
+        sbx = sby;
+        pax[0] = pay[0];
+        pax[1] = pay[1];
+    };
     int j = 0;
     while (j < J) {
         // generic until the next tile-pair boundary (at least one half-step: guarantees progress)
@@ -700,7 +681,12 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
             generic_half(j);
             ++j;
         } while ((j & 3) != 0 && j < J);
-        if (j + 4 > fast_last || moved_a || max_would_move(sbx, m_b)) continue;
+        if (j + 4 > fast_last || moved_a || redo_a) continue;
+        {   // B(j) must be safe to exponentiate with its stale max (inside the loop the look-ahead guarantees it)
+            float xa, xb;
+            rowmax16(sbx, m_b, xa, xb);
+            if (__any((half_swap_max(fmaxf(xa, xb)) - m_b) * p.scale_log2 > THR)) continue;
+        }
         // fast tile pairs
         while (j + 4 <= fast_last) {
             const int n = n_min + (j >> 1);
@@ -709,7 +695,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
                 load_v(n + 1, 1);
             }
             if (fast_half(I0{}, I0{}, sbx, sby, pax, pay)) {
-                sbx = sby; pax[0] = pay[0]; pax[1] = pay[1];
+                to_canonical_after_odd();
                 j += 1;
                 break;
             }
@@ -721,7 +707,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
                 load_v(n + 2, 0);
             }
             if (fast_half(I1{}, I0{}, sbx, sby, pax, pay)) {
-                sbx = sby; pax[0] = pay[0]; pax[1] = pay[1];
+                to_canonical_after_odd();
                 j += 3;
                 break;
             }

@@ -132,10 +132,10 @@ def test_local_window(sq, sk, window):
     k = torch.randn(2, sk, 2, 64, dtype=torch.bfloat16)
     v = torch.randn(2, sk, 2, 64, dtype=torch.bfloat16)
     out, lse, _ = fa.flash_attn_func(q.to(DEV), k.to(DEV), v.to(DEV), window_size=window, return_attn_probs=True)
-    # One-sided windows: the reference's kernel path makes the other side unbounded
+    # One-sided windows: the reference's kernel path sets the other side to seqlen_k
     # (set_params_fprop, csrc/flash_attn/flash_api.cpp:141-142) while its test-util mask builder takes a -1 right
     # window literally when left >= 0 (tests/test_util.py:176-182; the reference's own tests never pass that
-    # combination).  The kernel semantics are the contract: give the oracle the equivalent two-sided window.
+    # combination).  The kernel-path semantics are the contract: give the oracle the same two-sided window.
     ref_window = (window[0], sk) if (window[0] >= 0 and window[1] < 0) else window
     out_ref, out_pt, lse_ref = _dense_ref(q, k, v, window_size=ref_window)
     _check(out, out_ref, out_pt, f"window={window}")
