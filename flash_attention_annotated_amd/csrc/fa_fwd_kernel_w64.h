@@ -40,8 +40,28 @@ namespace fa {
 // non-transcendental VALU reader of its result, which hipcc pads only for its own instructions -- the order
 // exp,exp,add,add,cvt keeps one instruction between every producer/consumer pair; (b) it keeps hipcc from packing
 // the adds into v_pk_add_f32 (slow beside MFMAs) and (c) one statement = one asm boundary pad.
+// front/back: the same step split in two statements so one MFMA can be issued between them (the wave issues in
+// order: [MFMA][fma fma exp exp][MFMA][add add cvt] keeps the matrix pipe fed every 32 cycles, while
+// [MFMA MFMA][7 VALU] stalls the second MFMA on the pipe and then leaves the pipe idle behind the VALU block).
 template <typename T> struct Exp2Pair;
 template <> struct Exp2Pair<__bf16> {
+    static __device__ __forceinline__ void front(float s0, float s1, float c, float mc, float &t0, float &t1) {
+        asm("v_fma_f32 %0, %2, %4, -%5\n\t"
+            "v_fma_f32 %1, %3, %4, -%5\n\t"
+            "v_exp_f32 %0, %0\n\t"
+            "v_exp_f32 %1, %1"
+            : "=&v"(t0), "=&v"(t1)
+            : "v"(s0), "v"(s1), "s"(c), "v"(mc));
+    }
+    static __device__ __forceinline__ uint32_t back(float t0, float t1, float &ps0, float &ps1) {
+        uint32_t pk;
+        asm("v_add_f32 %1, %1, %3\n\t"
+            "v_add_f32 %2, %2, %4\n\t"
+            "v_cvt_pk_bf16_f32 %0, %3, %4"
+            : "=&v"(pk), "+v"(ps0), "+v"(ps1)
+            : "v"(t0), "v"(t1));
+        return pk;
+    }
     static __device__ __forceinline__ uint32_t run(float s0, float s1, float c, float mc, float &ps0, float &ps1) {
         uint32_t pk;
         float t0, t1;
@@ -58,6 +78,26 @@ template <> struct Exp2Pair<__bf16> {
     }
 };
 template <> struct Exp2Pair<_Float16> {
+    static __device__ __forceinline__ void front(float s0, float s1, float c, float mc, float &t0, float &t1) {
+        asm("v_fma_f32 %0, %2, %4, -%5\n\t"
+            "v_fma_f32 %1, %3, %4, -%5\n\t"
+            "v_exp_f32 %0, %0\n\t"
+            "v_exp_f32 %1, %1"
+            : "=&v"(t0), "=&v"(t1)
+            : "v"(s0), "v"(s1), "s"(c), "v"(mc));
+    }
+    static __device__ __forceinline__ uint32_t back(float t0, float t1, float &ps0, float &ps1) {
+        uint32_t pk;
+        float h0, h1;
+        asm("v_add_f32 %1, %1, %5\n\t"
+            "v_add_f32 %2, %2, %6\n\t"
+            "v_cvt_f16_f32 %3, %5\n\t"
+            "v_cvt_f16_f32 %4, %6\n\t"
+            "v_pack_b32_f16 %0, %3, %4"
+            : "=&v"(pk), "+v"(ps0), "+v"(ps1), "=&v"(h0), "=&v"(h1)
+            : "v"(t0), "v"(t1));
+        return pk;
+    }
     static __device__ __forceinline__ uint32_t run(float s0, float s1, float c, float mc, float &ps0, float &ps1) {
         uint32_t pk;
         float t0, t1;
@@ -601,16 +641,22 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
                 if (ks + 2 < KSTEPS) kf2 = k_frag(ks + 2);
                 else if (ks + 2 == KSTEPS) vfa = v_frag(0);
                 else vfb = v_frag(1);
-                if (ks == 0) {
-                    Mfma<T>::s_first(sa, kf0, qa[0]);
-                    Mfma<T>::s_first(sb_nxt, kf0, qb[0]);
-                } else {
-                    Mfma<T>::s_acc(sa, kf0, qa[ks]);
-                    Mfma<T>::s_acc(sb_nxt, kf0, qb[ks]);
-                }
+                // [MFMA A][fma fma exp exp][MFMA B][add add cvt] (+ further pairs when PER > 2)
+                if (ks == 0) Mfma<T>::s_first(sa, kf0, qa[0]);
+                else Mfma<T>::s_acc(sa, kf0, qa[ks]);
+                __builtin_amdgcn_sched_barrier(0);
+                float t0 = 0.f, t1 = 0.f;
+                if (!(FA_ABLATE & 1)) Exp2Pair<T>::front(sb_cur[ks * PER], sb_cur[ks * PER + 1], csc, mcb, t0, t1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (ks == 0) Mfma<T>::s_first(sb_nxt, kf0, qb[0]);
+                else Mfma<T>::s_acc(sb_nxt, kf0, qb[ks]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (!(FA_ABLATE & 1)) {
+                    pb[(ks * PER) >> 3][((ks * PER) & 7) >> 1] = Exp2Pair<T>::back(t0, t1, ps0, ps1);
 #pragma unroll
-                for (int e = ks * PER; e < (ks + 1) * PER && !(FA_ABLATE & 1); e += 2)
-                    pb[e >> 3][(e & 7) >> 1] = Exp2Pair<T>::run(sb_cur[e], sb_cur[e + 1], csc, mcb, ps0, ps1);
+                    for (int e = ks * PER + 2; e < (ks + 1) * PER; e += 2)
+                        pb[e >> 3][(e & 7) >> 1] = Exp2Pair<T>::run(sb_cur[e], sb_cur[e + 1], csc, mcb, ps0, ps1);
+                }
                 kf0 = kf1;
                 kf1 = kf2;
                 __builtin_amdgcn_sched_barrier(0);
@@ -632,11 +678,19 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
                 const int db = t >> 1, st = t & 1;
                 if (t == 0) Mfma<T>::o_acc_fence(oa[db], vf, pa_cur[st], sa, sb_nxt);
                 else Mfma<T>::o_acc(oa[db], vf, pa_cur[st]);
+                __builtin_amdgcn_sched_barrier(0);
+                float t0 = 0.f, t1 = 0.f;
+                if (!(FA_ABLATE & 2)) Exp2Pair<T>::front(sa[t * PER], sa[t * PER + 1], csc, mca, t0, t1);
+                __builtin_amdgcn_sched_barrier(0);
                 Mfma<T>::o_acc(ob[db], vf, pb[st]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (!(FA_ABLATE & 2)) {
+                    pa_nxt[(t * PER) >> 3][((t * PER) & 7) >> 1] = Exp2Pair<T>::back(t0, t1, ps0, ps1);
 #pragma unroll
-                for (int e = t * PER; e < (t + 1) * PER && !(FA_ABLATE & 2); e += 2)
-                    pa_nxt[e >> 3][(e & 7) >> 1] = Exp2Pair<T>::run(sa[e], sa[e + 1], csc, mca, ps0, ps1);
-                if (t == NSTEP / 2 && !(FA_ABLATE & 2)) rowmax16(sb_nxt, m_b, nxa, nxb);  // look-ahead max of B(j+1)
+                    for (int e = t * PER + 2; e < (t + 1) * PER; e += 2)
+                        pa_nxt[e >> 3][(e & 7) >> 1] = Exp2Pair<T>::run(sa[e], sa[e + 1], csc, mca, ps0, ps1);
+                    if (t == NSTEP / 2) rowmax16(sb_nxt, m_b, nxa, nxb);  // look-ahead max of B(j+1)
+                }
                 vf = vf_next;
                 vf_next = vf_next2;
                 __builtin_amdgcn_sched_barrier(0);
