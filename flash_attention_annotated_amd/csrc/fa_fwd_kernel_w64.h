@@ -16,9 +16,10 @@
 //     next phase 1 (after the PV MFMAs that still use the old scale have been issued).
 //     Role of the intra-warpgroup overlap of hopper/mainloop_fwd_sm90_tma_gmma_ws.hpp:1170-1207.
 //   * K tiles are staged SHIFTED by 32 keys (K tile m = keys [64m-32, 64m+32)) so that the two score halves
-//     computed during V tile n both come from K tile n+1: K and V are each double-buffered in LDS with one
-//     barrier per 64 keys; global loads for K(n+2)/V(n+1) are issued at the top of tile n and written to LDS
-//     at its end.
+//     computed during V tile n both come from K tile n+1.  K and V each live in a ring of 3 LDS buffers
+//     (tile t in buffer (t - n_min) % 3); the LDS-DMA for K(n+3)/V(n+2) is issued at the top of tile n and only
+//     has to have landed at the END of tile n+1 (counted vmcnt), i.e. it has two tiles of compute to hide under;
+//     one barrier per 64 keys.
 #pragma once
 
 #include "fa_fwd_kernel.h"
@@ -229,9 +230,20 @@ __device__ __forceinline__ void lds_dma(uint32_t lds, const void *base, const ui
             : "memory");
     }
 }
-// all LDS-DMA of this wave has landed and every wave has reached the end of the tile
+// End of a tile: all but this wave's N youngest LDS-DMA pieces have landed (the N issued at the top of THIS tile
+// may stay in flight: they fill buffers nobody reads before the next-but-one barrier), then the workgroup barrier.
+template <int N>
 __device__ __forceinline__ void tile_barrier() {
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    static_assert(N == 0 || N == 2 || N == 4 || N == 8, "pieces in flight");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+__device__ __forceinline__ void tile_barrier_n(int n_in_flight, int ld) {  // generic path: n in {0, ld, 2 ld}
+    if (n_in_flight >= 2 * ld) { if (ld == 4) tile_barrier<8>(); else tile_barrier<4>(); }
+    else if (n_in_flight >= ld) { if (ld == 4) tile_barrier<4>(); else tile_barrier<2>(); }
+    else tile_barrier<0>();
 }
 
 __device__ __forceinline__ void drain_scores(f32x16 &s0, f32x16 &s1) {
@@ -259,7 +271,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     constexpr float THR = (float)FA_RESCALE_THR;
     static_assert(D == 64 || D == 128, "w64 shape is built for head-dim tiles 64 and 128");
 
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // [K0 | K1 | V0 | V1]
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [K0 | K1 | K2 | V0 | V1 | V2]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -408,7 +420,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     };
     // K tile m = keys [64m - 32, 64m + 32)
     auto load_k = [&](int m, int buf) { dma_tile(kp, k_rs, p.k_row_stride, koff, m * BLOCK_N - 32, lds_wave + buf * TILE_BYTES); };
-    auto load_v = [&](int n, int buf) { dma_tile(vp, v_rs, p.v_row_stride, voff, n * BLOCK_N, lds_wave + (2 + buf) * TILE_BYTES); };
+    auto load_v = [&](int n, int buf) { dma_tile(vp, v_rs, p.v_row_stride, voff, n * BLOCK_N, lds_wave + (3 + buf) * TILE_BYTES); };
 
     // ---- lane parts of the LDS read addresses; everything else is an immediate or one XOR ---------------
     const int i16 = lane & 15, g1 = (lane >> 4) & 1;
@@ -434,7 +446,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     // Element j of lane half hh of 16-key step st is key 16st + 8(j>>2) + 4hh + (j&3).
     // s0/s1: the score tiles written by the preceding asm MFMAs (fenced behind the first MFMA issued here).
     auto pv_half = [&](int vbuf, int kh, const u32x4 (&pa)[2], const u32x4 (&pb)[2], f32x16 &s0, f32x16 &s1) {
-        const char *base = smem + (2 + vbuf) * TILE_BYTES + kh * (32 * ROWB);
+        const char *base = smem + (3 + vbuf) * TILE_BYTES + kh * (32 * ROWB);
 #pragma unroll
         for (int db = 0; db < DBLOCKS; ++db) {
 #pragma unroll
@@ -523,6 +535,16 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
         else
             asm volatile("s_nop 15\n\ts_nop 7" : "+a"(o[0]), "+a"(o[1]));
     };
+    // Same for ALL accumulators at once.  hipcc is free to move an accumulator to another AGPR tuple at any block
+    // boundary (v_accvgpr_mov right behind the asm MFMA that produced it = an unpadded MFMA->VALU read); every place
+    // where compiler-visible code may follow asm PV MFMAs (generic PV, fast-loop exits) therefore ends in this drain.
+    auto drain_all = [&]() {
+        if constexpr (DBLOCKS == 4)
+            asm volatile("s_nop 15\n\ts_nop 7" : "+a"(oa[0]), "+a"(oa[1]), "+a"(oa[2]), "+a"(oa[3]),
+                         "+a"(ob[0]), "+a"(ob[1]), "+a"(ob[2]), "+a"(ob[3]));
+        else
+            asm volatile("s_nop 15\n\ts_nop 7" : "+a"(oa[0]), "+a"(oa[1]), "+a"(ob[0]), "+a"(ob[1]));
+    };
     auto rescale = [&](f32x16 (&o)[DBLOCKS], float alpha) {
         drain_mfma(o);
 #pragma unroll
@@ -537,9 +559,12 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
         load_k(n_min, 0);
         load_v(n_min, 0);
         load_k(n_min + 1, 1);
+        if (n_min + 2 <= n_max) load_k(n_min + 2, 2);
+        if (n_min + 1 < n_max) load_v(n_min + 1, 1);
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): Q has landed; nothing compiler-visible stays pending
-    tile_barrier();                      // first tiles landed (asm LDS-DMA) and visible to every wave
+    tile_barrier<0>();                   // first tiles landed (asm LDS-DMA) and visible to every wave
+    int in_flight = 0;                   // LDS-DMA pieces this wave issued at the top of the current tile
 
     // Pipeline state at the boundary in front of half-step j (canonical naming):
     //   sbx = S_B(j) (masked, not yet exponentiated), pax = P_A(j), (m_a, l_a) through j, (m_b, l_b) through
@@ -563,10 +588,12 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     bool redo_a = false;      // P_A(j) / l_a were produced with a stale max that turned out too small: redo from sa
     float l_a_saved = 0.f;
     auto generic_half = [&](int j) {
-        const int i = j >> 1, kb = j & 1, slot = i & 1, n = n_min + i;
-        if (kb == 0) {  // K tile n+2 over K tile n, V tile n+1 over V tile n-1 (last read in tile n-1)
-            if (n + 2 <= n_max) load_k(n + 2, slot);
-            if (n + 1 < n_max) load_v(n + 1, slot ^ 1);
+        const int i = j >> 1, kb = j & 1, slot = i % 3, n = n_min + i;
+        const int slot1 = slot == 2 ? 0 : slot + 1, slot2 = slot == 0 ? 2 : slot - 1;  // (slot+1)%3, (slot+2)%3
+        if (kb == 0) {  // K tile n+3 over K tile n, V tile n+2 over V tile n-1 (both last read during tile n-1)
+            in_flight = 0;
+            if (n + 3 <= n_max) { load_k(n + 3, slot); in_flight += LD_PER_THREAD; }
+            if (n + 2 < n_max) { load_v(n + 2, slot2); in_flight += LD_PER_THREAD; }
         }
         if (j < jend) {
             if (redo_a) {  // sa still holds S_A(j)
@@ -577,12 +604,13 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
             if (moved_a) rescale(oa, alpha_a);  // deferred from softmax A(j)
             moved_a = false;
             if (j + 1 < jend) {
-                qk_half(slot ^ 1, kb, sa, sby);
+                qk_half(slot1, kb, sa, sby);
                 softmax(sbx, pb, m_b, l_b, alpha_b, moved_b);
                 if (moved_b) rescale(ob, alpha_b);
                 drain_scores(sa, sby);
                 prep_scores(j + 1, sa, sby);
                 pv_half(slot, kb, pax, pb, sa, sby);
+                drain_all();
                 softmax(sa, pay, m_a, l_a, alpha_a, moved_a);
                 sbx = sby;
                 pax[0] = pay[0];
@@ -591,9 +619,11 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
                 softmax(sbx, pb, m_b, l_b, alpha_b, moved_b);
                 if (moved_b) rescale(ob, alpha_b);
                 pv_half(slot, kb, pax, pb, sa, sby);
+                drain_all();
             }
         }
-        if (kb == 1) tile_barrier();  // this tile's LDS-DMA has landed; every wave is done with the old buffers
+        // tiles n+1's K/V (issued one tile ago) have landed; every wave is done with this tile's buffers
+        if (kb == 1) tile_barrier_n(in_flight, LD_PER_THREAD);
     };
     // ---- fast half-step: interior of the sweep (no masks, a next half-step exists).  The running max is NOT
     //      recomputed here: P = exp2(S*c - m_stale*c) and the per-lane partial row sums, which are needed anyway,
@@ -608,8 +638,8 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     auto fast_half = [&](auto slot_c, auto kb_c, f32x16 &sb_cur, f32x16 &sb_nxt, u32x4 (&pa_cur)[2],
                          u32x4 (&pa_nxt)[2]) -> bool {
         constexpr int SLOT = decltype(slot_c)::value, KB = decltype(kb_c)::value;
-        const char *kb_base = smem + (SLOT ^ 1) * TILE_BYTES + KB * (32 * ROWB);
-        const char *vb_base = smem + (2 + SLOT) * TILE_BYTES + KB * (32 * ROWB);
+        const char *kb_base = smem + ((SLOT + 1) % 3) * TILE_BYTES + KB * (32 * ROWB);
+        const char *vb_base = smem + (3 + SLOT) * TILE_BYTES + KB * (32 * ROWB);
         auto k_frag = [&](int ks) { return *(const u32x4 *)(kb_base + (kbase ^ (32 * ks))); };
         auto v_frag = [&](int t) {  // step t = (db, st)
             const int db = t >> 1, st = t & 1;
@@ -728,53 +758,66 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
         pax[0] = pay[0];
         pax[1] = pay[1];
     };
+    using I2 = std::integral_constant<int, 2>;
     int j = 0;
     while (j < J) {
-        // generic until the next tile-pair boundary (at least one half-step: guarantees progress)
+        // generic until the next 3-tile boundary (at least one half-step: guarantees progress)
         do {
             generic_half(j);
             ++j;
-        } while ((j & 3) != 0 && j < J);
-        if (j + 4 > fast_last || moved_a || redo_a) continue;
+        } while ((j % 6) != 0 && j < J);
+        if (j + 6 > fast_last || moved_a || redo_a) continue;
         {   // B(j) must be safe to exponentiate with its stale max (inside the loop the look-ahead guarantees it)
             float xa, xb;
             rowmax16(sbx, m_b, xa, xb);
             if (__any((half_swap_max(fmaxf(xa, xb)) - m_b) * p.scale_log2 > THR)) continue;
         }
-        // fast tile pairs
-        while (j + 4 <= fast_last) {
+        // fast: three tiles (one turn of the LDS rings) per iteration; every fast tile issues 2 LD_PER_THREAD pieces
+        while (j + 6 <= fast_last) {
             const int n = n_min + (j >> 1);
-            if (!(FA_ABLATE & 4)) {
-                load_k(n + 2, 0);
-                load_v(n + 1, 1);
+            int done = 0;        // half-steps completed in this iteration
+            bool odd_exit = false;
+            if (!(FA_ABLATE & 4)) { load_k(n + 3, 0); load_v(n + 2, 2); }
+            bool x = fast_half(I0{}, I0{}, sbx, sby, pax, pay);
+            done = 1; odd_exit = true;
+            if (!x) {
+                x = fast_half(I0{}, I1{}, sby, sbx, pay, pax);
+                if (!(FA_ABLATE & 8)) tile_barrier<2 * LD_PER_THREAD>();
+                done = 2; odd_exit = false;
             }
-            if (fast_half(I0{}, I0{}, sbx, sby, pax, pay)) {
-                to_canonical_after_odd();
-                j += 1;
+            if (!x) {
+                if (!(FA_ABLATE & 4)) { load_k(n + 4, 1); load_v(n + 3, 0); }
+                x = fast_half(I1{}, I0{}, sbx, sby, pax, pay);
+                done = 3; odd_exit = true;
+            }
+            if (!x) {
+                x = fast_half(I1{}, I1{}, sby, sbx, pay, pax);
+                if (!(FA_ABLATE & 8)) tile_barrier<2 * LD_PER_THREAD>();
+                done = 4; odd_exit = false;
+            }
+            if (!x) {
+                if (!(FA_ABLATE & 4)) { load_k(n + 5, 2); load_v(n + 4, 1); }
+                x = fast_half(I2{}, I0{}, sbx, sby, pax, pay);
+                done = 5; odd_exit = true;
+            }
+            if (!x) {
+                x = fast_half(I2{}, I1{}, sby, sbx, pay, pax);
+                if (!(FA_ABLATE & 8)) tile_barrier<2 * LD_PER_THREAD>();
+                done = 6; odd_exit = false;
+            }
+            j += done;
+            in_flight = 2 * LD_PER_THREAD;
+            if (x) {
+                if (odd_exit) to_canonical_after_odd();
                 break;
             }
-            const bool x1 = fast_half(I0{}, I1{}, sby, sbx, pay, pax);
-            if (!(FA_ABLATE & 8)) tile_barrier();
-            if (x1) { j += 2; break; }
-            if (!(FA_ABLATE & 4)) {
-                load_k(n + 3, 1);
-                load_v(n + 2, 0);
-            }
-            if (fast_half(I1{}, I0{}, sbx, sby, pax, pay)) {
-                to_canonical_after_odd();
-                j += 3;
-                break;
-            }
-            const bool x3 = fast_half(I1{}, I1{}, sby, sbx, pay, pax);
-            if (!(FA_ABLATE & 8)) tile_barrier();
-            j += 4;
-            if (x3) break;
         }
+        drain_all();  // leaving the fast loop: compiler-visible code may touch the accumulators from here on
     }
 
     // ---- epilogue ---------------------------------------------------------------------------------------
-    drain_mfma(oa);  // asm MFMA results -> VALU readers
-    drain_mfma(ob);
+    tile_barrier<0>();  // every wave's LDS-DMA (incl. look-ahead tiles past the end) has landed: the ring can be reused
+    drain_all();        // asm MFMA results -> VALU readers
     const float lt_a = half_swap_sum(l_a), lt_b = half_swap_sum(l_b);
     const bool e_a = (lt_a == 0.f) || (lt_a != lt_a), e_b = (lt_b == 0.f) || (lt_b != lt_b);
     const float inv_a = e_a ? 1.f : 1.f / lt_a, inv_b = e_b ? 1.f : 1.f / lt_b;
@@ -816,7 +859,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
 
 template <int D>
 constexpr int smem_bytes_w64() {
-    constexpr int kv = 4 * BLOCK_N * D * 2;
+    constexpr int kv = 6 * BLOCK_N * D * 2;
     constexpr int o = 4 * 64 * (D * 2 + 16);
     return kv > o ? kv : o;
 }

@@ -8,6 +8,7 @@ Usage: python tools/isa_hazards.py file.s  -> prints violations, exit code 1 if 
 import re
 import sys
 
+MFMA_RESULT_STATES = 11  # 8-pass XDL result -> any non-MFMA reader (what hipcc pads for its own MFMAs: s_nop 10)
 REQUIRED = 2  # the guide's figure; the scan is run with a margin (see tests/test_isa_hazards.py)
 
 
@@ -30,6 +31,7 @@ def scan(path, required=REQUIRED):
     kernel = None
     window = []  # (states_so_far_after, dst_regs, text, lineno) of recent VALU writes
     last_trans = None  # (dst_regs, text, lineno) when the previous instruction was a transcendental
+    mfma_out = []      # (states since issue, dst regs, text, lineno) of recent MFMAs
     for lineno, raw in enumerate(open(path), 1):
         l = raw.strip()
         m = re.match(r'^(_Z\w+):', l)
@@ -56,6 +58,20 @@ def scan(path, required=REQUIRED):
             last_trans = (regs(l.split(None, 1)[1].split(',')[0]), l, lineno)
         elif op not in ('s_waitcnt',):
             last_trans = None
+        # MFMA result read (or overwritten) by anything but a chained MFMA before the matrix pipe has written it
+        if ' ' in l and (op.startswith('v_') or op.startswith('ds_') or op.startswith('global_') or op.startswith('buffer_')):
+            toks = [t.strip().lstrip('-') for t in l.split(None, 1)[1].split(',')]
+            touched = set()
+            for t in toks:
+                touched |= regs(t)
+            for dist, dst, text, ln in mfma_out:
+                if dist < MFMA_RESULT_STATES and (dst & touched):
+                    if op.startswith('v_mfma'):
+                        # allowed: accumulate chain (same tuple as SrcC and vDst); anything else is flagged
+                        if regs(toks[0]) == dst and regs(toks[-1].split()[0]) == dst and not (
+                                (regs(toks[1]) | regs(toks[2])) & dst):
+                            continue
+                    violations.append((kernel, ln, text, lineno, l, dist))
         if op.startswith('v_mfma'):
             ops = l.split(None, 1)[1].split(',')
             srcs = set()
@@ -72,7 +88,10 @@ def scan(path, required=REQUIRED):
                 states = int(l.split()[1]) + 1
             elif op in ('s_waitcnt', 's_barrier') or op.startswith(';'):
                 states = 0  # may retire without spending an issue cycle: do not count on it
-        # age the window
+        # age the windows
+        mfma_out = [(d + states, dst, t, ln) for d, dst, t, ln in mfma_out if d + states < MFMA_RESULT_STATES + 1]
+        if op.startswith('v_mfma'):
+            mfma_out.append((0, regs(l.split(None, 1)[1].split(',')[0]), l, lineno))
         window = [(d + states, dst, t, ln) for d, dst, t, ln in window if d + states < required + 1]
         if op.startswith('v_') and not op.startswith('v_mfma') and not op.startswith('v_cmp'):
             dst = regs(l.split(None, 1)[1].split(',')[0]) if ' ' in l else set()
