@@ -198,6 +198,71 @@ template <> struct Mfma<_Float16> {
             : "+a"(o), "+v"(s0), "+v"(s1) : "v"(v), "v"(pf));
     }
 };
+
+// ---- fused slice of the fast path: ONE asm statement = two MFMAs (q-blocks A and B, same LDS fragment) interleaved
+// with the softmax step of two scores:
+//     MFMA A ; t0 = exp2(s0*c - mc) ; t1 = exp2(s1*c - mc) ; MFMA B ; ps0 += t0 ; ps1 += t1 ; pk = pack(t0, t1)
+// The wave is alone on its SIMD and issues in order, so this text order IS the schedule: ~24 cycles of VALU issue
+// behind each MFMA keep the matrix pipe fed every 32 cycles.  One statement per slice also means a single hipcc
+// asm-boundary pad per slice, and the exp -> add distance (one MFMA) satisfies gfx950's transcendental forwarding rule.
+// score_slice<FIRST>: score tiles (D in VGPRs; B = Q pinned in AGPRs as in/out operands); FIRST: D = A.B + 0
+// out_slice<FENCE>  : O accumulate (D in AGPRs, A = V^T fragment, B = P^T fragments in VGPRs); FENCE = first slice of a
+//                     phase: s_nop 1 in front (VALU-written P -> MFMA operand) and s_nop 3 behind the first MFMA (the
+//                     fma that follows reads score registers written by asm MFMAs of the previous phase)
+#define FA_FUSED_SLICE(MN, CVT_S, CVT_O)                                                                             \
+    template <bool FIRST>                                                                                            \
+    static __device__ __forceinline__ uint32_t score_slice(f32x16 &da, u32x4 &qa, f32x16 &db, u32x4 &qb, u32x4 kf,    \
+                                                           float s0, float s1, float c, float mc, float &ps0,        \
+                                                           float &ps1) {                                             \
+        uint32_t pk;                                                                                                 \
+        float t0, t1;                                                                                                \
+        if constexpr (FIRST)                                                                                         \
+            asm(MN " %0, %9, %1, 0\n\tv_fma_f32 %7, %10, %12, -%13\n\tv_fma_f32 %8, %11, %12, -%13\n\t"              \
+                   "v_exp_f32 %7, %7\n\tv_exp_f32 %8, %8\n\t" MN " %2, %9, %3, 0\n\t"                                \
+                   "v_add_f32 %5, %5, %7\n\tv_add_f32 %6, %6, %8\n\t" CVT_S                                          \
+                : "=&v"(da), "+a"(qa), "=&v"(db), "+a"(qb), "=&v"(pk), "+v"(ps0), "+v"(ps1), "=&v"(t0), "=&v"(t1)     \
+                : "v"(kf), "v"(s0), "v"(s1), "s"(c), "v"(mc));                                                       \
+        else                                                                                                         \
+            asm(MN " %0, %9, %1, %0\n\tv_fma_f32 %7, %10, %12, -%13\n\tv_fma_f32 %8, %11, %12, -%13\n\t"             \
+                   "v_exp_f32 %7, %7\n\tv_exp_f32 %8, %8\n\t" MN " %2, %9, %3, %2\n\t"                               \
+                   "v_add_f32 %5, %5, %7\n\tv_add_f32 %6, %6, %8\n\t" CVT_S                                          \
+                : "+v"(da), "+a"(qa), "+v"(db), "+a"(qb), "=&v"(pk), "+v"(ps0), "+v"(ps1), "=&v"(t0), "=&v"(t1)       \
+                : "v"(kf), "v"(s0), "v"(s1), "s"(c), "v"(mc));                                                       \
+        return pk;                                                                                                   \
+    }                                                                                                                \
+    template <bool FENCE>                                                                                            \
+    static __device__ __forceinline__ uint32_t out_slice(f32x16 &oa, u32x4 pa, f32x16 &ob, u32x4 pb, u32x4 vf,        \
+                                                         float s0, float s1, float c, float mc, float &ps0,          \
+                                                         float &ps1) {                                               \
+        uint32_t pk;                                                                                                 \
+        float t0, t1;                                                                                                \
+        if constexpr (FENCE)                                                                                         \
+            asm("s_nop 1\n\t" MN " %0, %7, %8, %0\n\ts_nop 3\n\tv_fma_f32 %5, %10, %12, -%13\n\t"                    \
+                "v_fma_f32 %6, %11, %12, -%13\n\tv_exp_f32 %5, %5\n\tv_exp_f32 %6, %6\n\t" MN " %1, %7, %9, %1\n\t"  \
+                "v_add_f32 %3, %3, %5\n\tv_add_f32 %4, %4, %6\n\t" CVT_O                                             \
+                : "+a"(oa), "+a"(ob), "=&v"(pk), "+v"(ps0), "+v"(ps1), "=&v"(t0), "=&v"(t1)                           \
+                : "v"(vf), "v"(pa), "v"(pb), "v"(s0), "v"(s1), "s"(c), "v"(mc));                                     \
+        else                                                                                                         \
+            asm(MN " %0, %7, %8, %0\n\tv_fma_f32 %5, %10, %12, -%13\n\t"                                             \
+                "v_fma_f32 %6, %11, %12, -%13\n\tv_exp_f32 %5, %5\n\tv_exp_f32 %6, %6\n\t" MN " %1, %7, %9, %1\n\t"  \
+                "v_add_f32 %3, %3, %5\n\tv_add_f32 %4, %4, %6\n\t" CVT_O                                             \
+                : "+a"(oa), "+a"(ob), "=&v"(pk), "+v"(ps0), "+v"(ps1), "=&v"(t0), "=&v"(t1)                           \
+                : "v"(vf), "v"(pa), "v"(pb), "v"(s0), "v"(s1), "s"(c), "v"(mc));                                     \
+        return pk;                                                                                                   \
+    }
+
+template <typename T> struct Fused;
+template <> struct Fused<__bf16> {
+    FA_FUSED_SLICE("v_mfma_f32_32x32x16_bf16", "v_cvt_pk_bf16_f32 %4, %7, %8", "v_cvt_pk_bf16_f32 %2, %5, %6")
+};
+template <> struct Fused<_Float16> {
+    // fp16 pack: two round-to-nearest-even converts, the second one into the high half of the same register (SDWA)
+    FA_FUSED_SLICE("v_mfma_f32_32x32x16_f16",
+                   "v_cvt_f16_f32 %4, %7\n\tv_cvt_f16_f32_sdwa %4, %8 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD",
+                   "v_cvt_f16_f32 %2, %5\n\tv_cvt_f16_f32_sdwa %2, %6 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD")
+};
+#undef FA_FUSED_SLICE
+
 // LDS-DMA of N consecutive 1-KiB pieces: piece i = 64 lanes x 16 B from (base + off[i]) to LDS byte address
 // lds + 1024 i.  Inline asm on purpose: hipcc cannot prove that the DMA destination does not alias later ds_reads
 // and drains vmcnt(0) right behind a __builtin_amdgcn_global_load_lds, serialising every tile load; asm loads
@@ -230,6 +295,12 @@ __device__ __forceinline__ void lds_dma(uint32_t lds, const void *base, const ui
             : "memory");
     }
 }
+// one piece (fast path: issued inside an MFMA slice so its ~50-100 issue cycles hide under the matrix pipe)
+__device__ __forceinline__ void lds_dma1(uint32_t lds, const void *base, uint32_t off) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(base), "s"(lds), "v"(off) : "memory");
+}
 // End of a tile: all but this wave's N youngest LDS-DMA pieces have landed (the N issued at the top of THIS tile
 // may stay in flight: they fill buffers nobody reads before the next-but-one barrier), then the workgroup barrier.
 template <int N>
@@ -252,7 +323,7 @@ __device__ __forceinline__ void drain_scores(f32x16 &s0, f32x16 &s1) {
 }
 
 // Developer-only timing ablations of the fast path (results are WRONG when non-zero; never shipped):
-// 1 = no phase-1 VALU, 2 = no phase-2 VALU, 4 = no K/V loads, 8 = no barriers.
+// 1 = no phase-1 VALU, 2 = no phase-2 VALU, 4 = no K/V loads, 8 = no barriers, 16 = no LDS fragment reads.
 #ifndef FA_ABLATE
 #define FA_ABLATE 0
 #endif
@@ -635,15 +706,24 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     //      (B's P is consumed in the same half-step, so B keeps a cheap max look-ahead in phase 2 instead of the sum
     //      guard.)  Returns true when the NEXT half-step must take the generic path; redo_a says A must be redone. --
     constexpr float LIM = (THR > 0.f) ? (float)(1u << (int)THR) : 1.0f;
+    // kf0/kf1: the first two K fragments of this half-step, fetched by the previous half-step (KB = 1) or by the
+    // driver right behind the tile barrier (KB = 0); a KB = 0 half-step leaves the next one's in them.
+    // kdma / vdma: wave-uniform source bases of K tile n+3 / V tile n+2 (both wholly inside the sequence); their
+    // LDS-DMA pieces are issued one per slice of the KB = 0 half-step, behind the slice's MFMAs.
     auto fast_half = [&](auto slot_c, auto kb_c, f32x16 &sb_cur, f32x16 &sb_nxt, u32x4 (&pa_cur)[2],
-                         u32x4 (&pa_nxt)[2]) -> bool {
+                         u32x4 (&pa_nxt)[2], u32x4 &kf0, u32x4 &kf1, const T *kdma, const T *vdma) -> bool {
         constexpr int SLOT = decltype(slot_c)::value, KB = decltype(kb_c)::value;
+        constexpr uint32_t KDST = SLOT * TILE_BYTES, VDST = (3 + (SLOT + 2) % 3) * TILE_BYTES;
         const char *kb_base = smem + ((SLOT + 1) % 3) * TILE_BYTES + KB * (32 * ROWB);
         const char *vb_base = smem + (3 + SLOT) * TILE_BYTES + KB * (32 * ROWB);
-        auto k_frag = [&](int ks) { return *(const u32x4 *)(kb_base + (kbase ^ (32 * ks))); };
+        auto k_frag = [&](int ks) {
+            if (FA_ABLATE & 16) return qa[ks];  // timing only: no LDS fragment reads
+            return *(const u32x4 *)(kb_base + (kbase ^ (32 * ks)));
+        };
         auto v_frag = [&](int t) {  // step t = (db, st)
             const int db = t >> 1, st = t & 1;
             u32x4 vf;
+            if (FA_ABLATE & 16) return qb[t];
 #pragma unroll
             for (int j2 = 0; j2 < 2; ++j2) {
                 const s16x4 x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(
@@ -664,29 +744,30 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
             constexpr int PER = 16 / KSTEPS;  // score elements of B(j) finished per k-step
             const float mcb = (m_b == -INFINITY ? 0.f : m_b) * csc;
             float ps0 = 0.f, ps1 = 0.f;
-            u32x4 kf0 = k_frag(0), kf1 = k_frag(1);
 #pragma unroll
             for (int ks = 0; ks < KSTEPS; ++ks) {
                 u32x4 kf2 = kf1;
                 if (ks + 2 < KSTEPS) kf2 = k_frag(ks + 2);
                 else if (ks + 2 == KSTEPS) vfa = v_frag(0);
                 else vfb = v_frag(1);
-                // [MFMA A][fma fma exp exp][MFMA B][add add cvt] (+ further pairs when PER > 2)
-                if (ks == 0) Mfma<T>::s_first(sa, kf0, qa[0]);
-                else Mfma<T>::s_acc(sa, kf0, qa[ks]);
-                __builtin_amdgcn_sched_barrier(0);
-                float t0 = 0.f, t1 = 0.f;
-                if (!(FA_ABLATE & 1)) Exp2Pair<T>::front(sb_cur[ks * PER], sb_cur[ks * PER + 1], csc, mcb, t0, t1);
-                __builtin_amdgcn_sched_barrier(0);
-                if (ks == 0) Mfma<T>::s_first(sb_nxt, kf0, qb[0]);
-                else Mfma<T>::s_acc(sb_nxt, kf0, qb[ks]);
-                __builtin_amdgcn_sched_barrier(0);
-                if (!(FA_ABLATE & 1)) {
-                    pb[(ks * PER) >> 3][((ks * PER) & 7) >> 1] = Exp2Pair<T>::back(t0, t1, ps0, ps1);
+                // MFMA A ; fma fma exp exp ; MFMA B ; add add cvt   (+ further pairs when PER > 2)
+                const int e = ks * PER;
+                if (FA_ABLATE & 1) {
+                    if (ks == 0) { Mfma<T>::s_first(sa, kf0, qa[0]); Mfma<T>::s_first(sb_nxt, kf0, qb[0]); }
+                    else { Mfma<T>::s_acc(sa, kf0, qa[ks]); Mfma<T>::s_acc(sb_nxt, kf0, qb[ks]); }
+                } else {
+                    if (ks == 0)
+                        pb[e >> 3][(e & 7) >> 1] = Fused<T>::template score_slice<true>(
+                            sa, qa[0], sb_nxt, qb[0], kf0, sb_cur[e], sb_cur[e + 1], csc, mcb, ps0, ps1);
+                    else
+                        pb[e >> 3][(e & 7) >> 1] = Fused<T>::template score_slice<false>(
+                            sa, qa[ks], sb_nxt, qb[ks], kf0, sb_cur[e], sb_cur[e + 1], csc, mcb, ps0, ps1);
 #pragma unroll
-                    for (int e = ks * PER + 2; e < (ks + 1) * PER; e += 2)
-                        pb[e >> 3][(e & 7) >> 1] = Exp2Pair<T>::run(sb_cur[e], sb_cur[e + 1], csc, mcb, ps0, ps1);
+                    for (int e2 = e + 2; e2 < e + PER; e2 += 2)
+                        pb[e2 >> 3][(e2 & 7) >> 1] = Exp2Pair<T>::run(sb_cur[e2], sb_cur[e2 + 1], csc, mcb, ps0, ps1);
                 }
+                if (KB == 0 && ks < LD_PER_THREAD && !(FA_ABLATE & 4))
+                    lds_dma1(lds_wave + KDST + ks * 1024, kdma, koff[ks < LD_PER_THREAD ? ks : 0]);
                 kf0 = kf1;
                 kf1 = kf2;
                 __builtin_amdgcn_sched_barrier(0);
@@ -706,21 +787,28 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
                 u32x4 vf_next2 = vf_next;
                 if (t + 2 < NSTEP) vf_next2 = v_frag(t + 2);
                 const int db = t >> 1, st = t & 1;
-                if (t == 0) Mfma<T>::o_acc_fence(oa[db], vf, pa_cur[st], sa, sb_nxt);
-                else Mfma<T>::o_acc(oa[db], vf, pa_cur[st]);
-                __builtin_amdgcn_sched_barrier(0);
-                float t0 = 0.f, t1 = 0.f;
-                if (!(FA_ABLATE & 2)) Exp2Pair<T>::front(sa[t * PER], sa[t * PER + 1], csc, mca, t0, t1);
-                __builtin_amdgcn_sched_barrier(0);
-                Mfma<T>::o_acc(ob[db], vf, pb[st]);
-                __builtin_amdgcn_sched_barrier(0);
-                if (!(FA_ABLATE & 2)) {
-                    pa_nxt[(t * PER) >> 3][((t * PER) & 7) >> 1] = Exp2Pair<T>::back(t0, t1, ps0, ps1);
+                // the first K fragments of the NEXT half-step ride in the last two slices (same tile: no barrier between)
+                if (KB == 0 && t == NSTEP - 2) kf0 = *(const u32x4 *)(kb_base + 32 * ROWB + (kbase ^ 0));
+                if (KB == 0 && t == NSTEP - 1) kf1 = *(const u32x4 *)(kb_base + 32 * ROWB + (kbase ^ 32));
+                const int e = t * PER;
+                if (FA_ABLATE & 2) {
+                    if (t == 0) Mfma<T>::o_acc_fence(oa[db], vf, pa_cur[st], sa, sb_nxt);
+                    else Mfma<T>::o_acc(oa[db], vf, pa_cur[st]);
+                    Mfma<T>::o_acc(ob[db], vf, pb[st]);
+                } else {
+                    if (t == 0)
+                        pa_nxt[e >> 3][(e & 7) >> 1] = Fused<T>::template out_slice<true>(
+                            oa[db], pa_cur[st], ob[db], pb[st], vf, sa[e], sa[e + 1], csc, mca, ps0, ps1);
+                    else
+                        pa_nxt[e >> 3][(e & 7) >> 1] = Fused<T>::template out_slice<false>(
+                            oa[db], pa_cur[st], ob[db], pb[st], vf, sa[e], sa[e + 1], csc, mca, ps0, ps1);
 #pragma unroll
-                    for (int e = t * PER + 2; e < (t + 1) * PER; e += 2)
-                        pa_nxt[e >> 3][(e & 7) >> 1] = Exp2Pair<T>::run(sa[e], sa[e + 1], csc, mca, ps0, ps1);
+                    for (int e2 = e + 2; e2 < e + PER; e2 += 2)
+                        pa_nxt[e2 >> 3][(e2 & 7) >> 1] = Exp2Pair<T>::run(sa[e2], sa[e2 + 1], csc, mca, ps0, ps1);
                     if (t == NSTEP / 2) rowmax16(sb_nxt, m_b, nxa, nxb);  // look-ahead max of B(j+1)
                 }
+                if (KB == 0 && t < LD_PER_THREAD && !(FA_ABLATE & 4))
+                    lds_dma1(lds_wave + VDST + t * 1024, vdma, voff[t < LD_PER_THREAD ? t : 0]);
                 vf = vf_next;
                 vf_next = vf_next2;
                 __builtin_amdgcn_sched_barrier(0);
@@ -742,6 +830,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     // last half-step index whose scores need no mask (for this wave), and the fast limit: every half-step
     // jj of a fast tile pair [j, j+4) needs jj + 1 <= fast_last
     int fast_last = -1;
+    const int seq_last = __builtin_amdgcn_readfirstlane((sk - n_min * BLOCK_N) / 32 - 1);  // last half-step wholly < sk
     if (!SOFTCAP && p.window_left < 0 && jend > 0) {
         int nomask = (sk - n_min * BLOCK_N) / 32 - 1;
         if (p.window_right >= 0) {
@@ -772,36 +861,44 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
             rowmax16(sbx, m_b, xa, xb);
             if (__any((half_swap_max(fmaxf(xa, xb)) - m_b) * p.scale_log2 > THR)) continue;
         }
-        // fast: three tiles (one turn of the LDS rings) per iteration; every fast tile issues 2 LD_PER_THREAD pieces
-        while (j + 6 <= fast_last) {
+        // fast: three tiles (one turn of the LDS rings) per iteration; every fast tile issues 2 LD_PER_THREAD pieces,
+        // all of them wholly inside the sequence (j + 10 <= seq_last), one per slice of its first half-step
+        while (j + 6 <= fast_last && j + 10 <= seq_last) {
             const int n = n_min + (j >> 1);
             int done = 0;        // half-steps completed in this iteration
             bool odd_exit = false;
-            if (!(FA_ABLATE & 4)) { load_k(n + 3, 0); load_v(n + 2, 2); }
-            bool x = fast_half(I0{}, I0{}, sbx, sby, pax, pay);
+            u32x4 kf0, kf1;      // first two K fragments of the next half-step (fetched behind the tile barrier)
+            auto k_prefetch = [&](int kbuf) {
+                kf0 = *(const u32x4 *)(smem + kbuf * TILE_BYTES + (kbase ^ 0));
+                kf1 = *(const u32x4 *)(smem + kbuf * TILE_BYTES + (kbase ^ 32));
+            };
+            auto k_src = [&](int m) { return kp + (int64_t)(m * BLOCK_N - 32) * p.k_row_stride; };
+            auto v_src = [&](int t) { return vp + (int64_t)(t * BLOCK_N) * p.v_row_stride; };
+            k_prefetch(1);       // tile slot 0 reads K buffer 1
+            bool x = fast_half(I0{}, I0{}, sbx, sby, pax, pay, kf0, kf1, k_src(n + 3), v_src(n + 2));
             done = 1; odd_exit = true;
             if (!x) {
-                x = fast_half(I0{}, I1{}, sby, sbx, pay, pax);
+                x = fast_half(I0{}, I1{}, sby, sbx, pay, pax, kf0, kf1, nullptr, nullptr);
                 if (!(FA_ABLATE & 8)) tile_barrier<2 * LD_PER_THREAD>();
                 done = 2; odd_exit = false;
             }
             if (!x) {
-                if (!(FA_ABLATE & 4)) { load_k(n + 4, 1); load_v(n + 3, 0); }
-                x = fast_half(I1{}, I0{}, sbx, sby, pax, pay);
+                k_prefetch(2);
+                x = fast_half(I1{}, I0{}, sbx, sby, pax, pay, kf0, kf1, k_src(n + 4), v_src(n + 3));
                 done = 3; odd_exit = true;
             }
             if (!x) {
-                x = fast_half(I1{}, I1{}, sby, sbx, pay, pax);
+                x = fast_half(I1{}, I1{}, sby, sbx, pay, pax, kf0, kf1, nullptr, nullptr);
                 if (!(FA_ABLATE & 8)) tile_barrier<2 * LD_PER_THREAD>();
                 done = 4; odd_exit = false;
             }
             if (!x) {
-                if (!(FA_ABLATE & 4)) { load_k(n + 5, 2); load_v(n + 4, 1); }
-                x = fast_half(I2{}, I0{}, sbx, sby, pax, pay);
+                k_prefetch(0);
+                x = fast_half(I2{}, I0{}, sbx, sby, pax, pay, kf0, kf1, k_src(n + 5), v_src(n + 4));
                 done = 5; odd_exit = true;
             }
             if (!x) {
-                x = fast_half(I2{}, I1{}, sby, sbx, pay, pax);
+                x = fast_half(I2{}, I1{}, sby, sbx, pay, pax, kf0, kf1, nullptr, nullptr);
                 if (!(FA_ABLATE & 8)) tile_barrier<2 * LD_PER_THREAD>();
                 done = 6; odd_exit = false;
             }
