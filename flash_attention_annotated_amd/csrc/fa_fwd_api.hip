@@ -32,7 +32,7 @@ int launch(const fa::KParams &kp, hipStream_t stream) {
         }
         attr_set.store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL(kernel, dim3(kp.num_tiles), dim3(NWAVES * 64), smem, stream, kp);
+    hipLaunchKernelGGL(kernel, dim3(kp.grid), dim3(NWAVES * 64), smem, stream, kp);
     if (hipGetLastError() != hipSuccess) return FA_ERR_LAUNCH;
     return FA_OK;
 }
@@ -49,7 +49,7 @@ int launch_w64(const fa::KParams &kp, hipStream_t stream) {
         }
         attr_set.store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL(kernel, dim3(kp.num_tiles), dim3(256), smem, stream, kp);
+    hipLaunchKernelGGL(kernel, dim3(kp.grid), dim3(256), smem, stream, kp);
     if (hipGetLastError() != hipSuccess) return FA_ERR_LAUNCH;
     return FA_OK;
 }
@@ -182,6 +182,13 @@ int fa_fwd(const fa_fwd_params *p, void *stream_) {
     if (tiles == 0) return FA_OK;  // nothing to compute (seqlen_q == 0)
     if (tiles > 0x7fffffff) return FA_ERR_BAD_SHAPE;
     kp.num_tiles = (int32_t)tiles;
+    // scheduling unit: everything that streams one (batch, kv head)'s K/V, unless that leaves fewer than two units
+    // per XCD; then one m_block of the GQA group (small problems: fill the chip first, L2 reuse second)
+    kp.unit_tiles = ((int64_t)p->b * p->h_k >= 16) ? kp.h_ratio * kp.num_m_blocks : kp.h_ratio;
+    const int64_t units = (tiles + kp.unit_tiles - 1) / kp.unit_tiles;
+    const int64_t grid = 8 * ((units + 7) / 8) * kp.unit_tiles;
+    if (grid > 0x7fffffff) return FA_ERR_BAD_SHAPE;
+    kp.grid = (int32_t)grid;
 
     // window normalisation: csrc/flash_attn/flash_api.cpp:396-402
     int wl = p->window_size_left, wr = p->window_size_right;

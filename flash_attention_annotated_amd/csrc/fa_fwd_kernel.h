@@ -51,7 +51,9 @@ struct KParams {
     int32_t b, seqlen_q, seqlen_k, h, h_k, d, total_q;
     int32_t h_ratio;       // h / h_k
     int32_t num_m_blocks;  // ceil(seqlen_q / BLOCK_M)
-    int32_t num_tiles;     // num_m_blocks * h * b
+    int32_t num_tiles;     // num_m_blocks * h * b  (work list length)
+    int32_t unit_tiles;    // tiles per scheduling unit (see decode_tile)
+    int32_t grid;          // workgroups launched = 8 * ceil(units / 8) * unit_tiles
     int32_t window_left, window_right;  // <0 unbounded; causal => right = 0
     float scale;           // softmax_scale (softcap: the softcap value)
     float scale_log2;      // scale * log2(e)
@@ -87,6 +89,28 @@ template <> struct Elem<_Float16> {
 };
 
 constexpr int BLOCK_N = 64;  // keys per K/V tile
+
+// ---- tile scheduler (role of hopper/tile_scheduler.hpp:36-136, 218-363) --------------------------------------------
+// Work list, in order: (batch, kv head, m_block descending = heaviest causal blocks first, q head of the GQA group).
+// It is cut into UNITS of `unit_tiles` consecutive tiles -- normally all tiles of one (batch, kv head), i.e. everything
+// that streams the same K/V -- and the units are dealt round-robin to the 8 XCDs: workgroup ids are dealt round-robin
+// over the XCDs by the dispatcher (wg % 8 labels the workgroups that share an L2), so XCD x runs units x, x+8, ...
+// one after the other.  Sharing workgroups hit one L2 (HBM traffic ~ algorithmic bytes), and XCDs get the same number of
+// units of every batch entry, which balances ragged batches (a contiguous split gave whole sequences to single XCDs).
+// Placement is a speed matter only.  Returns false for padding workgroups.
+__device__ __forceinline__ bool decode_tile(const KParams &p, int &m_block, int &head, int &batch) {
+    const int wg = blockIdx.x;
+    const int xcd = wg & 7, slot = wg >> 3;
+    const int unit = (slot / p.unit_tiles) * 8 + xcd;
+    const int tile = unit * p.unit_tiles + slot % p.unit_tiles;
+    if (tile >= p.num_tiles) return false;
+    const int per_kvh = p.h_ratio * p.num_m_blocks;
+    const int bk = tile / per_kvh, r = tile % per_kvh;
+    batch = bk / p.h_k;
+    m_block = p.num_m_blocks - 1 - r / p.h_ratio;
+    head = (bk % p.h_k) * p.h_ratio + r % p.h_ratio;
+    return true;
+}
 
 // Byte offset of 16-byte chunk `ch` of row `row` inside a [rows][D] 16-bit LDS tile.
 // The XOR keeps (a) ds_read_b128 of 16 lanes reading the same chunk of 16 rows distinct mod 16 and
@@ -147,22 +171,8 @@ __global__ __launch_bounds__(NWAVES * 64, (D <= 128 ? 2 : 1)) void fwd_kernel(co
     const int r = lane & 31;
     const int hh = lane >> 5;
 
-    // ---- tile scheduler: XCD-aware linear tile id -> (m_block, head, batch) --------------------
-    // Workgroups are dealt round-robin over the 8 XCDs; give each XCD a contiguous chunk of the
-    // (batch, head, m_block) list so workgroups sharing one K/V head share one L2.
-    int tile;
-    {
-        const int wg = blockIdx.x;
-        const int nwg = p.num_tiles;
-        const int xcd = wg & 7, slot = wg >> 3;
-        const int q8 = nwg >> 3, r8 = nwg & 7;
-        tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
-    }
-    const int mi = tile % p.num_m_blocks;
-    const int bh = tile / p.num_m_blocks;
-    const int m_block = p.num_m_blocks - 1 - mi;  // heaviest (causal) blocks first
-    const int head = bh % p.h;
-    const int batch = bh / p.h;
+    int m_block, head, batch;
+    if (!decode_tile(p, m_block, head, batch)) return;  // whole workgroup (padding)
     const int kv_head = head / p.h_ratio;
 
     // ---- sequence bookkeeping (BlockInfo / SeqlenInfo role) --------------------------------------

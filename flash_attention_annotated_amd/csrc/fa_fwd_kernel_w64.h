@@ -350,20 +350,8 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     const int r = lane & 31;
     const int hh = lane >> 5;
 
-    // ---- tile scheduler (XCD-aware), identical to fwd_kernel ------------------------------------------
-    int tile;
-    {
-        const int wg = blockIdx.x;
-        const int nwg = p.num_tiles;
-        const int xcd = wg & 7, slot = wg >> 3;
-        const int q8 = nwg >> 3, r8 = nwg & 7;
-        tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
-    }
-    const int mi = tile % p.num_m_blocks;
-    const int bh = tile / p.num_m_blocks;
-    const int m_block = p.num_m_blocks - 1 - mi;
-    const int head = bh % p.h;
-    const int batch = bh / p.h;
+    int m_block, head, batch;
+    if (!decode_tile(p, m_block, head, batch)) return;  // whole workgroup (padding)
     const int kv_head = head / p.h_ratio;
 
     int sq, sk;
@@ -397,6 +385,13 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     const T *kp = (const T *)p.k + k_base + (int64_t)kv_head * p.k_head_stride;
     const T *vp = (const T *)p.v + v_base + (int64_t)kv_head * p.v_head_stride;
     T *op = (T *)p.o + o_base + (int64_t)head * p.o_head_stride;
+
+    // The few kernel arguments the main loop needs, detached from the kernarg SGPR tuples (hipcc loads the by-value
+    // struct as s_load_dwordx8/x16 tuples and, once those spill, reloads a whole tuple through v_readlane -- VALU
+    // instructions -- every tile just to reach one field).  The empty asm makes each one a fresh scalar value.
+    int64_t k_rs64 = p.k_row_stride, v_rs64 = p.v_row_stride;
+    float csc_arg = p.scale_log2;
+    asm volatile("" : "+s"(k_rs64), "+s"(v_rs64), "+s"(csc_arg));
 
     const int shift = sk - sq;
     const int row_hi = min(sq, row_lo + BLOCK_M);
@@ -455,7 +450,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     // (duplicates are masked / meet zero Q chunks: see fa_fwd_kernel.h).  Loads are branch-free.
     int ld_row[LD_PER_THREAD], ld_col[LD_PER_THREAD];
     uint32_t koff[LD_PER_THREAD], voff[LD_PER_THREAD];  // byte offsets of this lane's chunks inside an in-range tile
-    const int k_rs = (int)p.k_row_stride, v_rs = (int)p.v_row_stride;
+    const int k_rs = (int)k_rs64, v_rs = (int)v_rs64;
 #pragma unroll
     for (int i = 0; i < LD_PER_THREAD; ++i) {
         const int slot = wave * (LD_PER_THREAD * 64) + i * 64 + lane;  // 16-byte slot index inside the tile image
@@ -490,8 +485,8 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
         }
     };
     // K tile m = keys [64m - 32, 64m + 32)
-    auto load_k = [&](int m, int buf) { dma_tile(kp, k_rs, p.k_row_stride, koff, m * BLOCK_N - 32, lds_wave + buf * TILE_BYTES); };
-    auto load_v = [&](int n, int buf) { dma_tile(vp, v_rs, p.v_row_stride, voff, n * BLOCK_N, lds_wave + (3 + buf) * TILE_BYTES); };
+    auto load_k = [&](int m, int buf) { dma_tile(kp, k_rs, k_rs64, koff, m * BLOCK_N - 32, lds_wave + buf * TILE_BYTES); };
+    auto load_v = [&](int n, int buf) { dma_tile(vp, v_rs, v_rs64, voff, n * BLOCK_N, lds_wave + (3 + buf) * TILE_BYTES); };
 
     // ---- lane parts of the LDS read addresses; everything else is an immediate or one XOR ---------------
     const int i16 = lane & 15, g1 = (lane >> 4) & 1;
@@ -591,7 +586,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
         alpha = __builtin_amdgcn_exp2f(m_run * p.scale_log2 - mc);
         m_run = m_eff;
         float ps0 = 0.f, ps1 = 0.f;
-        const float csc = p.scale_log2;  // kernarg: wave-uniform, lives in an SGPR
+        const float csc = csc_arg;  // wave-uniform, lives in an SGPR
 #pragma unroll
         for (int i = 0; i < 16; i += 2)
             pf[i >> 3][(i & 7) >> 1] = Exp2Pair<T>::run(s[i], s[i + 1], csc, mc, ps0, ps1);
@@ -734,7 +729,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
             }
             return vf;
         };
-        const float csc = p.scale_log2;  // kernarg: wave-uniform, lives in an SGPR
+        const float csc = csc_arg;  // wave-uniform, lives in an SGPR
 
         // ---------- phase 1: S(j+1) = K.Q^T on the matrix pipe || exp/sum/pack of B(j) on the VALU ----------
         // LDS fragments are fetched two slices (>= 128 cycles) ahead of the MFMA that consumes them; the first
@@ -859,7 +854,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
         {   // B(j) must be safe to exponentiate with its stale max (inside the loop the look-ahead guarantees it)
             float xa, xb;
             rowmax16(sbx, m_b, xa, xb);
-            if (__any((half_swap_max(fmaxf(xa, xb)) - m_b) * p.scale_log2 > THR)) continue;
+            if (__any((half_swap_max(fmaxf(xa, xb)) - m_b) * csc_arg > THR)) continue;
         }
         // fast: three tiles (one turn of the LDS rings) per iteration; every fast tile issues 2 LD_PER_THREAD pieces,
         // all of them wholly inside the sequence (j + 10 <= seq_last), one per slice of its first half-step
@@ -872,8 +867,8 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
                 kf0 = *(const u32x4 *)(smem + kbuf * TILE_BYTES + (kbase ^ 0));
                 kf1 = *(const u32x4 *)(smem + kbuf * TILE_BYTES + (kbase ^ 32));
             };
-            auto k_src = [&](int m) { return kp + (int64_t)(m * BLOCK_N - 32) * p.k_row_stride; };
-            auto v_src = [&](int t) { return vp + (int64_t)(t * BLOCK_N) * p.v_row_stride; };
+            auto k_src = [&](int m) { return kp + (int64_t)(m * BLOCK_N - 32) * k_rs64; };
+            auto v_src = [&](int t) { return vp + (int64_t)(t * BLOCK_N) * v_rs64; };
             k_prefetch(1);       // tile slot 0 reads K buffer 1
             bool x = fast_half(I0{}, I0{}, sbx, sby, pax, pay, kf0, kf1, k_src(n + 3), v_src(n + 2));
             done = 1; odd_exit = true;
