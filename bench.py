@@ -32,6 +32,9 @@ WORKLOADS = {
     "c3": ("C3 b4 h16 d128 s16384 bf16 causal", 4, 16, 16, 16384, 128, True, None),
     "c4": ("C4 varlen GQA hq32 hkv8 d128 lens 8192..1024 bf16 non-causal", 8, 32, 8, 8192, 128, False,
            [8192, 7168, 6144, 5120, 4096, 3072, 2048, 1024]),
+    # C5: fp8 e4m3 inputs (bf16 output), descales = 1; global batch 32 strong-scaled in BASELINE.md -> here 4 per GPU
+    "c5": ("C5 fp8 e4m3 b4 h16 d128 s8192 non-causal (fp8 storage, exact bf16 expansion pass + bf16 MFMA)", 4, 16, 16,
+           8192, 128, False, None),
 }
 
 
@@ -68,6 +71,12 @@ def measured_traffic(workload_key):
 def make_inputs(w, device, seed):
     import torch
     _, b, h, hk, s, d, causal, lens = w
+    if w[0].startswith("C5"):
+        g = torch.Generator(device=device).manual_seed(seed)
+        mk = lambda hh: torch.randn(b, s, hh, d, device=device, dtype=torch.bfloat16, generator=g).to(torch.float8_e4m3fn)
+        q, k, v = mk(h), mk(hk), mk(hk)
+        ones = torch.ones(b, hk, device=device, dtype=torch.float32)
+        return (q, k, v), {"fp8": True, "descale": ones}
     g = torch.Generator(device=device).manual_seed(seed)
     if lens is None:
         q = torch.randn(b, s, h, d, device=device, dtype=torch.bfloat16, generator=g)
@@ -120,7 +129,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))  # c2 = BASELINE metric config
     ap.add_argument("--variant", type=int, default=0, help="kernel variant override (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -155,6 +164,10 @@ def main():
     (q, k, v), extra = make_inputs(w, device, seed=rank)  # each rank: its own batch shard, already in HBM
 
     def step():
+        if "fp8" in extra:
+            from flash_attention_annotated_amd import hopper_interface as fa3
+            d1 = extra["descale"]
+            return fa3.flash_attn_func(q, k, v, causal=w[6], q_descale=d1, k_descale=d1, v_descale=d1)
         if "cu" in extra:
             return fa.flash_attn_varlen_func(q, k, v, extra["cu"], extra["cu"], extra["max"], extra["max"],
                                              causal=w[6])
@@ -203,7 +216,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "bf16",
+            "dtype": "fp8_e4m3 storage / bf16 MFMA" if args.workload == "c5" else "bf16",
             "data": "synthetic (torch.randn N(0,1), seed = rank)",
             "config": {"workload": w[0], "batch_per_gpu": w[1], "heads_q": w[2], "heads_kv": w[3], "seqlen": w[4],
                        "head_dim": w[5], "causal": w[6], "sharding": f"batch shard x{world}, no collective"},

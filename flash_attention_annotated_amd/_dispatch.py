@@ -1,0 +1,77 @@
+"""Shared host glue: torch tensors -> fa_fwd_params -> fa_fwd on torch's current stream.  Used by the FA2-shaped
+module (flash_attn_2_cuda.py) and the FA3-shaped one (flash_attn_3_cuda.py).  No compute happens here."""
+import ctypes
+
+import torch
+
+from . import _lib
+
+_DT = {torch.float16: _lib.FA_DTYPE_FP16, torch.bfloat16: _lib.FA_DTYPE_BF16}
+if hasattr(torch, "float8_e4m3fn"):
+    _DT[torch.float8_e4m3fn] = _lib.FA_DTYPE_FP8_E4M3
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def aligned(t):
+    """The kernels move 16-byte vectors (the fp8 expansion pass 8-byte ones): bases and the non-unit strides must keep
+    rows aligned.  Views that are not get copied by the callers."""
+    esz = t.element_size()
+    if t.data_ptr() % (16 if esz == 2 else 8) != 0:
+        return False
+    return all(s % 8 == 0 for s in t.stride()[:-1])
+
+
+def launch(q, k, v, out, lse, *, varlen, batch, max_seqlen_q, max_seqlen_k, softmax_scale, causal, window_left,
+           window_right, softcap, cu_seqlens_q=None, cu_seqlens_k=None, seqused_q=None, seqused_k=None,
+           q_descale=None, k_descale=None, v_descale=None):
+    """q/k/v/out: dense (b, s, h, d) or packed (total, h, d) tensors on one GPU, last stride 1, aligned()."""
+    lib = _lib.load()
+    prm = _lib.new_params()
+    prm.q, prm.k, prm.v, prm.o = ptr(q), ptr(k), ptr(v), ptr(out)
+    prm.softmax_lse = ptr(lse)
+    if varlen:
+        for name, t in (("q", q), ("k", k), ("v", v), ("o", out)):
+            setattr(prm, f"{name}_batch_stride", 0)
+            setattr(prm, f"{name}_row_stride", t.stride(0))
+            setattr(prm, f"{name}_head_stride", t.stride(1))
+        prm.total_q, prm.total_k = q.shape[0], k.shape[0]
+        prm.h, prm.h_k, prm.d = q.shape[1], k.shape[1], q.shape[2]
+    else:
+        for name, t in (("q", q), ("k", k), ("v", v), ("o", out)):
+            setattr(prm, f"{name}_batch_stride", t.stride(0))
+            setattr(prm, f"{name}_row_stride", t.stride(1))
+            setattr(prm, f"{name}_head_stride", t.stride(2))
+        prm.total_q = prm.total_k = 0
+        prm.h, prm.h_k, prm.d = q.shape[2], k.shape[2], q.shape[3]
+    prm.b, prm.seqlen_q, prm.seqlen_k = int(batch), int(max_seqlen_q), int(max_seqlen_k)
+    prm.dtype = _DT[q.dtype]
+    prm.cu_seqlens_q, prm.cu_seqlens_k = ptr(cu_seqlens_q), ptr(cu_seqlens_k)
+    prm.seqused_q, prm.seqused_k = ptr(seqused_q), ptr(seqused_k)
+    prm.softmax_scale = float(softmax_scale)
+    prm.softcap = float(softcap)
+    prm.is_causal = int(bool(causal))
+    prm.window_size_left, prm.window_size_right = int(window_left), int(window_right)
+    for name, t in (("q", q_descale), ("k", k_descale), ("v", v_descale)):
+        setattr(prm, f"{name}_descale", ptr(t))
+        if t is not None:
+            setattr(prm, f"{name}_descale_batch_stride", t.stride(0))
+            setattr(prm, f"{name}_descale_head_stride", t.stride(1))
+    workspace = None
+    need = lib.fa_fwd_workspace_size(ctypes.byref(prm))
+    if need < 0:
+        raise RuntimeError(f"fa_fwd_workspace_size failed ({need}): {_lib.strerror(int(need))}")
+    if need > 0:  # fp8: scratch for the bf16 expansion, from torch's caching allocator (callee never allocates)
+        workspace = torch.empty(int(need) + 256, dtype=torch.uint8, device=q.device)
+        base = (workspace.data_ptr() + 255) // 256 * 256
+        prm.workspace = ctypes.c_void_p(base)
+        prm.workspace_bytes = int(need)
+    stream = torch.cuda.current_stream(q.device).cuda_stream
+    st = lib.fa_fwd(ctypes.byref(prm), ctypes.c_void_p(stream))
+    if st != 0:
+        raise RuntimeError(f"fa_fwd failed ({st}): {_lib.strerror(st)}")
+    if workspace is not None:
+        workspace.record_stream(torch.cuda.current_stream(q.device))
+    return out, lse

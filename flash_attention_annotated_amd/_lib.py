@@ -14,13 +14,14 @@ LIB_PATH = os.path.join(_HERE, LIB_NAME)
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
-FA_ABI_VERSION = 1
+FA_ABI_VERSION = 2
 FA_DTYPE_FP16, FA_DTYPE_BF16, FA_DTYPE_FP8_E4M3 = 0, 1, 2
 
 # every symbol include/fa_fwd.h declares (tests check the .so exports all of them)
 EXPORTED_SYMBOLS = (
     "fa_fwd",
     "fa_fwd_validate",
+    "fa_fwd_workspace_size",
     "fa_strerror",
     "fa_fwd_params_size",
     "fa_abi_version",
@@ -79,7 +80,9 @@ class FaFwdParams(ctypes.Structure):
         ("v_descale_batch_stride", ctypes.c_int64),
         ("v_descale_head_stride", ctypes.c_int64),
         ("kernel_variant", ctypes.c_int32),
-        ("reserved0", ctypes.c_int32),
+        ("total_k", ctypes.c_int32),
+        ("workspace", ctypes.c_void_p),
+        ("workspace_bytes", ctypes.c_uint64),
     ]
 
 
@@ -119,6 +122,8 @@ def load():
     lib.fa_fwd.restype = ctypes.c_int
     lib.fa_fwd_validate.argtypes = [ctypes.POINTER(FaFwdParams)]
     lib.fa_fwd_validate.restype = ctypes.c_int
+    lib.fa_fwd_workspace_size.argtypes = [ctypes.POINTER(FaFwdParams)]
+    lib.fa_fwd_workspace_size.restype = ctypes.c_int64
     lib.fa_strerror.argtypes = [ctypes.c_int]
     lib.fa_strerror.restype = ctypes.c_char_p
     lib.fa_fwd_params_size.argtypes = []

@@ -7,12 +7,60 @@
 #include "fa_fwd_kernel.h"
 #include "fa_fwd_kernel_w64.h"
 
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 
 namespace {
 
 std::atomic<int> g_default_variant{0};
+
+// ---- fp8 e4m3 -> bf16 expansion (exact), strided source -> contiguous (rows, heads, d) destination ------------------
+// One thread = 8 elements (8-byte load, 16-byte store).  HBM-bound elementwise pass.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__global__ void expand_fp8_kernel(const uint8_t *__restrict__ src, uint32_t *__restrict__ dst, int64_t rows,
+                                  int rows_per_batch, int heads, int d, int64_t batch_stride, int64_t row_stride,
+                                  int64_t head_stride) {
+    const int chunks = d >> 3;
+    const int64_t total = rows * heads * chunks;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % chunks);
+        const int64_t rh = i / chunks;
+        const int hd = (int)(rh % heads);
+        const int64_t row = rh / heads;
+        const int64_t b = rows_per_batch > 0 ? row / rows_per_batch : 0;
+        const int64_t r = rows_per_batch > 0 ? row % rows_per_batch : row;
+        const uint2 v = *reinterpret_cast<const uint2 *>(src + b * batch_stride + r * row_stride + hd * head_stride + c * 8);
+        uint32_t out[4];
+        const uint32_t w[2] = {v.x, v.y};
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const f32x2_t lo = __builtin_amdgcn_cvt_pk_f32_fp8(w[k], false);
+            const f32x2_t hi = __builtin_amdgcn_cvt_pk_f32_fp8(w[k], true);
+            const bf16x2_t a = {(__bf16)lo[0], (__bf16)lo[1]};
+            const bf16x2_t bq = {(__bf16)hi[0], (__bf16)hi[1]};
+            out[2 * k] = __builtin_bit_cast(uint32_t, a);
+            out[2 * k + 1] = __builtin_bit_cast(uint32_t, bq);
+        }
+        *reinterpret_cast<uint4 *>(dst + i * 4) = make_uint4(out[0], out[1], out[2], out[3]);
+    }
+}
+
+int64_t align256(int64_t x) { return (x + 255) & ~int64_t(255); }
+
+struct Fp8Plan {
+    int64_t rows_q, rows_k, q_bytes, kv_bytes, total;
+};
+Fp8Plan fp8_plan(const fa_fwd_params *p) {
+    Fp8Plan pl;
+    pl.rows_q = p->cu_seqlens_q ? p->total_q : (int64_t)p->b * p->seqlen_q;
+    pl.rows_k = p->cu_seqlens_q ? p->total_k : (int64_t)p->b * p->seqlen_k;
+    pl.q_bytes = align256(pl.rows_q * p->h * p->d * 2);
+    pl.kv_bytes = align256(pl.rows_k * p->h_k * p->d * 2);
+    pl.total = pl.q_bytes + 2 * pl.kv_bytes;
+    return pl;
+}
 
 int head_dim_tile(int d) {
     if (d <= 64) return 64;
@@ -110,6 +158,7 @@ const char *fa_strerror(int status) {
         case FA_ERR_LAUNCH: return "kernel launch failed";
         case FA_ERR_BAD_ABI: return "fa_fwd_params abi_version/struct_size mismatch";
         case FA_ERR_NO_DEVICE: return "no gfx950 device";
+        case FA_ERR_WORKSPACE: return "fp8 inputs need a 256-byte aligned workspace of fa_fwd_workspace_size() bytes";
         default: return "unknown status";
     }
 }
@@ -123,12 +172,23 @@ int fa_fwd_tile_shape(int32_t d, int32_t dtype, int32_t is_causal, int32_t *bloc
     return FA_OK;
 }
 
+int64_t fa_fwd_workspace_size(const fa_fwd_params *p) {
+    if (!p) return FA_ERR_NULL_POINTER;
+    if (p->abi_version != FA_ABI_VERSION || p->struct_size != sizeof(fa_fwd_params)) return FA_ERR_BAD_ABI;
+    if (p->dtype != FA_DTYPE_FP8_E4M3) return 0;
+    if (p->b <= 0 || p->h <= 0 || p->h_k <= 0 || p->d <= 0 || p->seqlen_q < 0 || p->seqlen_k < 0) return FA_ERR_BAD_SHAPE;
+    if (p->cu_seqlens_q && (p->total_q < 0 || p->total_k < 0)) return FA_ERR_BAD_SHAPE;
+    return fp8_plan(p).total;
+}
+
 int fa_fwd_validate(const fa_fwd_params *p) {
     if (!p) return FA_ERR_NULL_POINTER;
     if (p->abi_version != FA_ABI_VERSION || p->struct_size != sizeof(fa_fwd_params)) return FA_ERR_BAD_ABI;
-    if (p->dtype != FA_DTYPE_FP16 && p->dtype != FA_DTYPE_BF16) return FA_ERR_BAD_DTYPE;  // fp8: not built yet
+    if (p->dtype != FA_DTYPE_FP16 && p->dtype != FA_DTYPE_BF16 && p->dtype != FA_DTYPE_FP8_E4M3) return FA_ERR_BAD_DTYPE;
     if (p->b <= 0 || p->h <= 0 || p->h_k <= 0 || p->seqlen_q < 0 || p->seqlen_k < 0) return FA_ERR_BAD_SHAPE;
     if (p->d <= 0 || p->d > 256 || p->d % 8 != 0) return FA_ERR_BAD_HEAD_DIM;
+    const bool fp8 = p->dtype == FA_DTYPE_FP8_E4M3;
+    if (fp8 && p->d % 16 != 0) return FA_ERR_BAD_HEAD_DIM;  // hopper/flash_api.cpp:854-856
     if (p->h % p->h_k != 0) return FA_ERR_BAD_HEADS;
     if ((p->cu_seqlens_q == nullptr) != (p->cu_seqlens_k == nullptr)) return FA_ERR_BAD_SHAPE;
     if (p->cu_seqlens_q && p->total_q < 0) return FA_ERR_BAD_SHAPE;
@@ -138,6 +198,7 @@ int fa_fwd_validate(const fa_fwd_params *p) {
         if (p->seqlen_k > 0 && (!p->k || !p->v)) return FA_ERR_NULL_POINTER;
     }
     // 16-byte vector loads/stores: bases and strides must keep every row 16-byte aligned
+    // (fp8 sources are read 8 bytes at a time by the expansion pass: same multiple-of-8-elements rule)
     const int64_t strides[] = {p->q_row_stride, p->q_head_stride, p->k_row_stride, p->k_head_stride,
                                p->v_row_stride, p->v_head_stride, p->o_row_stride, p->o_head_stride};
     for (int64_t s : strides)
@@ -152,7 +213,12 @@ int fa_fwd_validate(const fa_fwd_params *p) {
     }
     const void *ptrs[] = {p->q, p->k, p->v, p->o};
     for (const void *ptr : ptrs)
-        if (reinterpret_cast<uintptr_t>(ptr) % 16 != 0) return FA_ERR_BAD_STRIDE;
+        if (reinterpret_cast<uintptr_t>(ptr) % (fp8 && ptr != p->o ? 8 : 16) != 0) return FA_ERR_BAD_STRIDE;
+    if (fp8 && !empty && p->seqlen_k > 0) {
+        if (!p->workspace || reinterpret_cast<uintptr_t>(p->workspace) % 256 != 0 ||
+            (int64_t)p->workspace_bytes < fp8_plan(p).total)
+            return FA_ERR_WORKSPACE;
+    }
     if (p->softcap < 0.f || std::isnan(p->softcap) || std::isnan(p->softmax_scale)) return FA_ERR_BAD_SHAPE;
     return FA_OK;
 }
@@ -168,11 +234,42 @@ int fa_fwd(const fa_fwd_params *p, void *stream_) {
 
     fa::KParams kp{};
     kp.q = p->q; kp.k = p->k; kp.v = p->v; kp.o = p->o; kp.lse = p->softmax_lse;
+    const bool fp8 = p->dtype == FA_DTYPE_FP8_E4M3;
+    const bool nothing = p->seqlen_q == 0 || p->seqlen_k == 0 || (p->cu_seqlens_q && p->total_q == 0);
+    int64_t ws_q_row = 0, ws_k_row = 0;
+    if (fp8 && !nothing) {
+        const Fp8Plan pl = fp8_plan(p);
+        char *ws = static_cast<char *>(p->workspace);
+        const int rpb_q = p->cu_seqlens_q ? 0 : p->seqlen_q, rpb_k = p->cu_seqlens_q ? 0 : p->seqlen_k;
+        auto expand = [&](const void *src, void *dst, int64_t rows, int rpb, int heads, int64_t bs, int64_t rs, int64_t hs) {
+            const int64_t total = rows * heads * (p->d / 8);
+            if (total == 0) return;
+            const int blocks = (int)std::min<int64_t>((total + 255) / 256, 256 * 8);
+            hipLaunchKernelGGL(expand_fp8_kernel, dim3(blocks), dim3(256), 0, stream, static_cast<const uint8_t *>(src),
+                               static_cast<uint32_t *>(dst), rows, rpb, heads, p->d, bs, rs, hs);
+        };
+        expand(p->q, ws, pl.rows_q, rpb_q, p->h, p->q_batch_stride, p->q_row_stride, p->q_head_stride);
+        expand(p->k, ws + pl.q_bytes, pl.rows_k, rpb_k, p->h_k, p->k_batch_stride, p->k_row_stride, p->k_head_stride);
+        expand(p->v, ws + pl.q_bytes + pl.kv_bytes, pl.rows_k, rpb_k, p->h_k, p->v_batch_stride, p->v_row_stride, p->v_head_stride);
+        if (hipGetLastError() != hipSuccess) return FA_ERR_LAUNCH;
+        kp.q = ws; kp.k = ws + pl.q_bytes; kp.v = ws + pl.q_bytes + pl.kv_bytes;
+        ws_q_row = (int64_t)p->h * p->d;
+        ws_k_row = (int64_t)p->h_k * p->d;
+    }
     kp.cu_seqlens_q = p->cu_seqlens_q; kp.cu_seqlens_k = p->cu_seqlens_k;
     kp.seqused_q = p->seqused_q; kp.seqused_k = p->seqused_k;
     kp.q_batch_stride = p->q_batch_stride; kp.q_row_stride = p->q_row_stride; kp.q_head_stride = p->q_head_stride;
     kp.k_batch_stride = p->k_batch_stride; kp.k_row_stride = p->k_row_stride; kp.k_head_stride = p->k_head_stride;
     kp.v_batch_stride = p->v_batch_stride; kp.v_row_stride = p->v_row_stride; kp.v_head_stride = p->v_head_stride;
+    if (fp8) {  // the expanded copies are contiguous (rows, heads, d)
+        kp.q_row_stride = ws_q_row; kp.q_head_stride = p->d; kp.q_batch_stride = ws_q_row * p->seqlen_q;
+        kp.k_row_stride = kp.v_row_stride = ws_k_row; kp.k_head_stride = kp.v_head_stride = p->d;
+        kp.k_batch_stride = kp.v_batch_stride = ws_k_row * p->seqlen_k;
+        kp.q_descale = p->q_descale; kp.k_descale = p->k_descale; kp.v_descale = p->v_descale;
+        kp.qd_bs = (int32_t)p->q_descale_batch_stride; kp.qd_hs = (int32_t)p->q_descale_head_stride;
+        kp.kd_bs = (int32_t)p->k_descale_batch_stride; kp.kd_hs = (int32_t)p->k_descale_head_stride;
+        kp.vd_bs = (int32_t)p->v_descale_batch_stride; kp.vd_hs = (int32_t)p->v_descale_head_stride;
+    }
     kp.o_batch_stride = p->o_batch_stride; kp.o_row_stride = p->o_row_stride; kp.o_head_stride = p->o_head_stride;
     kp.b = p->b; kp.seqlen_q = p->seqlen_q; kp.seqlen_k = p->seqlen_k; kp.h = p->h; kp.h_k = p->h_k; kp.d = p->d;
     kp.total_q = p->total_q;
@@ -215,7 +312,7 @@ int fa_fwd(const fa_fwd_params *p, void *stream_) {
         kp.scale_log2 = p->softmax_scale * kLog2e;
     }
 
-    if (p->dtype == FA_DTYPE_BF16) return dispatch_hdim<__bf16>(kp, softcap, variant, stream);
+    if (p->dtype == FA_DTYPE_BF16 || fp8) return dispatch_hdim<__bf16>(kp, softcap, variant, stream);  // fp8: out is bf16
     return dispatch_hdim<_Float16>(kp, softcap, variant, stream);
 }
 

@@ -58,7 +58,30 @@ struct KParams {
     float scale;           // softmax_scale (softcap: the softcap value)
     float scale_log2;      // scale * log2(e)
     float softcap_pre;     // softmax_scale / softcap (0 when softcap is off)
+    // fp8 inputs: per-(batch, kv head) fp32 dequantisation factors (NULL = 1).  q*k is folded into the softmax scale,
+    // v into the final O normalisation (hopper/flash_fwd_kernel_sm90.h:408-415, mainloop_fwd_sm90...hpp:1241-1250).
+    const float *q_descale, *k_descale, *v_descale;
+    int32_t qd_bs, qd_hs, kd_bs, kd_hs, vd_bs, vd_hs;  // element strides (batch, head)
 };
+
+// per-workgroup effective scales for (batch, kv_head)
+struct Scales {
+    float scale, scale_log2, softcap_pre, v_descale;
+};
+__device__ __forceinline__ Scales load_scales(const KParams &p, int batch, int kv_head) {
+    float qk = 1.f, vd = 1.f;
+    if (p.q_descale) qk *= p.q_descale[batch * p.qd_bs + kv_head * p.qd_hs];
+    if (p.k_descale) qk *= p.k_descale[batch * p.kd_bs + kv_head * p.kd_hs];
+    if (p.v_descale) vd = p.v_descale[batch * p.vd_bs + kv_head * p.vd_hs];
+    Scales s;
+    if (p.softcap_pre != 0.f) {  // softcap: tanh((q.k * qk) * scale / cap) * cap -> only the pre-factor sees qk
+        s.scale = p.scale; s.scale_log2 = p.scale_log2; s.softcap_pre = p.softcap_pre * qk;
+    } else {
+        s.scale = p.scale * qk; s.scale_log2 = p.scale_log2 * qk; s.softcap_pre = 0.f;
+    }
+    s.v_descale = vd;
+    return s;
+}
 
 template <typename T> struct Elem;
 template <> struct Elem<__bf16> {
@@ -202,6 +225,7 @@ __global__ __launch_bounds__(NWAVES * 64, (D <= 128 ? 2 : 1)) void fwd_kernel(co
     }
     const int row_lo = m_block * BLOCK_M;
     if (row_lo >= sq) return;  // whole workgroup: nothing to do (varlen / padded grid)
+    const Scales sc = load_scales(p, batch, kv_head);
 
     const T *qp = (const T *)p.q + q_base + (int64_t)head * p.q_head_stride;
     const T *kp = (const T *)p.k + k_base + (int64_t)kv_head * p.k_head_stride;
@@ -332,7 +356,7 @@ __global__ __launch_bounds__(NWAVES * 64, (D <= 128 ? 2 : 1)) void fwd_kernel(co
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) s[kb][i] = fast_tanh(s[kb][i] * p.softcap_pre);
+                    for (int i = 0; i < 16; ++i) s[kb][i] = fast_tanh(s[kb][i] * sc.softcap_pre);
             }
 
             // ---- mask (boundary tiles only) -----------------------------------------------------
@@ -356,9 +380,9 @@ __global__ __launch_bounds__(NWAVES * 64, (D <= 128 ? 2 : 1)) void fwd_kernel(co
             for (int i = 1; i < 16; ++i) mx = max3(mx, s[0][i], s[1][i]);
             const float m_new = half_swap_max(mx);  // >= m_run (m_run is identical in both halves)
             const float m_use = (m_new == -INFINITY) ? 0.f : m_new;  // fully masked so far
-            const float mc = m_use * p.scale_log2;
+            const float mc = m_use * sc.scale_log2;
             if (__any(m_new > m_run)) {  // wave-uniform; bit-identical to always rescaling
-                const float alpha = __builtin_amdgcn_exp2f(m_run * p.scale_log2 - mc);
+                const float alpha = __builtin_amdgcn_exp2f(m_run * sc.scale_log2 - mc);
                 l_run *= alpha;
 #pragma unroll
                 for (int db = 0; db < DBLOCKS; ++db)
@@ -371,7 +395,7 @@ __global__ __launch_bounds__(NWAVES * 64, (D <= 128 ? 2 : 1)) void fwd_kernel(co
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const float pv = __builtin_amdgcn_exp2f(s[kb][i] * p.scale_log2 - mc);
+                    const float pv = __builtin_amdgcn_exp2f(s[kb][i] * sc.scale_log2 - mc);
                     s[kb][i] = pv;
                     psum += pv;
                 }
@@ -417,11 +441,11 @@ __global__ __launch_bounds__(NWAVES * 64, (D <= 128 ? 2 : 1)) void fwd_kernel(co
     // (the loop's last barrier has retired every K/V read, so the region can be reused)
     const float l_tot = half_swap_sum(l_run);
     const bool empty = (l_tot == 0.f) || (l_tot != l_tot);
-    const float inv = empty ? 1.f : 1.f / l_tot;
+    const float inv = (empty ? 1.f : 1.f / l_tot) * sc.v_descale;
     if (wave_active) {
         if (hh == 0 && my_row < sq) {
             // csrc/flash_attn/src/softmax.h:178-180: +inf for rows with no valid key
-            p.lse[lse_base + my_row] = empty ? INFINITY : m_run * p.scale + __logf(l_tot);
+            p.lse[lse_base + my_row] = empty ? INFINITY : m_run * sc.scale + __logf(l_tot);
         }
         char *obuf = smem + wave * (32 * O_ROW_BYTES);
 #pragma unroll

@@ -389,8 +389,10 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     // The few kernel arguments the main loop needs, detached from the kernarg SGPR tuples (hipcc loads the by-value
     // struct as s_load_dwordx8/x16 tuples and, once those spill, reloads a whole tuple through v_readlane -- VALU
     // instructions -- every tile just to reach one field).  The empty asm makes each one a fresh scalar value.
+    const Scales sc = load_scales(p, batch, kv_head);
     int64_t k_rs64 = p.k_row_stride, v_rs64 = p.v_row_stride;
-    float csc_arg = p.scale_log2;
+    // (scale * descale is a VALU product: bring it back to an SGPR by value, not by int conversion)
+    float csc_arg = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sc.scale_log2)));
     asm volatile("" : "+s"(k_rs64), "+s"(v_rs64), "+s"(csc_arg));
 
     const int shift = sk - sq;
@@ -544,8 +546,8 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
         if constexpr (SOFTCAP) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                sa[i] = fast_tanh(sa[i] * p.softcap_pre);
-                sb[i] = fast_tanh(sb[i] * p.softcap_pre);
+                sa[i] = fast_tanh(sa[i] * sc.softcap_pre);
+                sb[i] = fast_tanh(sb[i] * sc.softcap_pre);
             }
         }
         if (half_needs_mask(j)) {
@@ -579,11 +581,11 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
             moved = __any(m_new > m_run);
             m_eff = m_new;
         } else {
-            moved = __any((m_new - m_run) * p.scale_log2 > THR);  // -inf -> finite counts as moved
+            moved = __any((m_new - m_run) * csc_arg > THR);  // -inf -> finite counts as moved
             m_eff = moved ? m_new : m_run;
         }
-        const float mc = (m_eff == -INFINITY ? 0.f : m_eff) * p.scale_log2;
-        alpha = __builtin_amdgcn_exp2f(m_run * p.scale_log2 - mc);
+        const float mc = (m_eff == -INFINITY ? 0.f : m_eff) * csc_arg;
+        alpha = __builtin_amdgcn_exp2f(m_run * csc_arg - mc);
         m_run = m_eff;
         float ps0 = 0.f, ps1 = 0.f;
         const float csc = csc_arg;  // wave-uniform, lives in an SGPR
@@ -912,12 +914,12 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     drain_all();        // asm MFMA results -> VALU readers
     const float lt_a = half_swap_sum(l_a), lt_b = half_swap_sum(l_b);
     const bool e_a = (lt_a == 0.f) || (lt_a != lt_a), e_b = (lt_b == 0.f) || (lt_b != lt_b);
-    const float inv_a = e_a ? 1.f : 1.f / lt_a, inv_b = e_b ? 1.f : 1.f / lt_b;
+    const float inv_a = (e_a ? 1.f : 1.f / lt_a) * sc.v_descale, inv_b = (e_b ? 1.f : 1.f / lt_b) * sc.v_descale;
     const bool wave_active = wrow < sq;
     if (wave_active) {
         if (hh == 0) {
-            if (row_a < sq) p.lse[lse_base + row_a] = e_a ? INFINITY : m_a * p.scale + __logf(lt_a);
-            if (row_b < sq) p.lse[lse_base + row_b] = e_b ? INFINITY : m_b * p.scale + __logf(lt_b);
+            if (row_a < sq) p.lse[lse_base + row_a] = e_a ? INFINITY : m_a * sc.scale + __logf(lt_a);
+            if (row_b < sq) p.lse[lse_base + row_b] = e_b ? INFINITY : m_b * sc.scale + __logf(lt_b);
         }
         char *obuf = smem + wave * (64 * O_ROW_BYTES);
 #pragma unroll

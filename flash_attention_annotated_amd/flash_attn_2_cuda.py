@@ -11,13 +11,13 @@ checks, output allocation, params — and enqueue the gfx950 kernel through the 
 
 Only the forward hot path is built: `bwd`, `varlen_bwd`, `fwd_kvcache` raise.
 """
-import ctypes
 import math
 from typing import List, Optional
 
 import torch
 
-from . import _lib
+from . import _dispatch, _lib
+from ._dispatch import aligned as _aligned
 
 __all__ = ["fwd", "varlen_fwd", "bwd", "varlen_bwd", "fwd_kvcache"]
 
@@ -41,26 +41,6 @@ def _check_device(x, name):
 
 def _check_shape(x, name, *shape):
     _check(tuple(x.shape) == tuple(shape), f"{name} must have shape ({', '.join(str(s) for s in shape)})")
-
-
-def _ptr(t):
-    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
-
-
-def _aligned(t):
-    """The kernel moves 16-byte vectors: rows must stay 16-byte aligned (any layout the
-    reference accepts with d % 8 == 0 and storage-aligned views does)."""
-    if t.data_ptr() % 16 != 0:
-        return False
-    return all(s % 8 == 0 for s in t.stride()[:-1])
-
-
-def _launch(params, device):
-    lib = _lib.load()
-    stream = torch.cuda.current_stream(device).cuda_stream
-    st = lib.fa_fwd(ctypes.byref(params), ctypes.c_void_p(stream))
-    if st != 0:
-        raise RuntimeError(f"fa_fwd failed ({st}): {_lib.strerror(st)}")
 
 
 def _reject_unbuilt(alibi_slopes_, p_dropout, return_softmax):
@@ -121,23 +101,9 @@ def fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out_: Optional[torch.
         if seqlen_k > 0 and seqlen_q > 0:
             qc, kc, vc = (x if _aligned(x) else x.contiguous() for x in (q, k, v))
             oc = out if _aligned(out) else torch.empty_like(qc)
-            prm = _lib.new_params()
-            prm.q, prm.k, prm.v, prm.o = _ptr(qc), _ptr(kc), _ptr(vc), _ptr(oc)
-            prm.softmax_lse = _ptr(softmax_lse)
-            prm.q_batch_stride, prm.q_row_stride, prm.q_head_stride = qc.stride(0), qc.stride(1), qc.stride(2)
-            prm.k_batch_stride, prm.k_row_stride, prm.k_head_stride = kc.stride(0), kc.stride(1), kc.stride(2)
-            prm.v_batch_stride, prm.v_row_stride, prm.v_head_stride = vc.stride(0), vc.stride(1), vc.stride(2)
-            prm.o_batch_stride, prm.o_row_stride, prm.o_head_stride = oc.stride(0), oc.stride(1), oc.stride(2)
-            prm.b, prm.seqlen_q, prm.seqlen_k = batch_size, seqlen_q, seqlen_k
-            prm.h, prm.h_k, prm.d = num_heads, num_heads_k, head_size
-            prm.total_q = 0
-            prm.dtype = _dtype_code(q)
-            prm.softmax_scale = float(softmax_scale)
-            prm.softcap = float(softcap)
-            prm.is_causal = int(bool(is_causal))
-            prm.window_size_left = int(window_size_left)
-            prm.window_size_right = int(window_size_right)
-            _launch(prm, q.device)
+            _dispatch.launch(qc, kc, vc, oc, softmax_lse, varlen=False, batch=batch_size, max_seqlen_q=seqlen_q,
+                             max_seqlen_k=seqlen_k, softmax_scale=softmax_scale, causal=is_causal,
+                             window_left=window_size_left, window_right=window_size_right, softcap=softcap)
             if oc is not out:
                 out.copy_(oc)
         elif seqlen_q > 0:
@@ -217,25 +183,10 @@ def varlen_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out_: Optional
         if max_seqlen_k > 0 and total_q > 0 and max_seqlen_q > 0:
             qc, kc, vc = (x if _aligned(x) else x.contiguous() for x in (q, k, v))
             oc = out if _aligned(out) else torch.empty_like(qc)
-            prm = _lib.new_params()
-            prm.q, prm.k, prm.v, prm.o = _ptr(qc), _ptr(kc), _ptr(vc), _ptr(oc)
-            prm.softmax_lse = _ptr(softmax_lse)
-            prm.q_batch_stride, prm.q_row_stride, prm.q_head_stride = 0, qc.stride(0), qc.stride(1)
-            prm.k_batch_stride, prm.k_row_stride, prm.k_head_stride = 0, kc.stride(0), kc.stride(1)
-            prm.v_batch_stride, prm.v_row_stride, prm.v_head_stride = 0, vc.stride(0), vc.stride(1)
-            prm.o_batch_stride, prm.o_row_stride, prm.o_head_stride = 0, oc.stride(0), oc.stride(1)
-            prm.b, prm.seqlen_q, prm.seqlen_k = batch_size, int(max_seqlen_q), int(max_seqlen_k)
-            prm.h, prm.h_k, prm.d = num_heads, num_heads_k, head_size
-            prm.total_q = total_q
-            prm.dtype = _dtype_code(q)
-            prm.cu_seqlens_q, prm.cu_seqlens_k = _ptr(cu_seqlens_q), _ptr(cu_seqlens_k)
-            prm.seqused_k = _ptr(seqused_k)
-            prm.softmax_scale = float(softmax_scale)
-            prm.softcap = float(softcap)
-            prm.is_causal = int(bool(is_causal))
-            prm.window_size_left = int(window_size_left)
-            prm.window_size_right = int(window_size_right)
-            _launch(prm, q.device)
+            _dispatch.launch(qc, kc, vc, oc, softmax_lse, varlen=True, batch=batch_size, max_seqlen_q=max_seqlen_q,
+                             max_seqlen_k=max_seqlen_k, softmax_scale=softmax_scale, causal=is_causal,
+                             window_left=window_size_left, window_right=window_size_right, softcap=softcap,
+                             cu_seqlens_q=cu_seqlens_q, cu_seqlens_k=cu_seqlens_k, seqused_k=seqused_k)
             if oc is not out:
                 out.copy_(oc)
         elif total_q > 0:

@@ -1,0 +1,116 @@
+"""FA3 operator surface: `flash_attn_3::fwd` (hopper/flash_api.cpp:672-1198; schema :1672-1707), as the Python
+callable `hopper/flash_attn_interface.py:66` invokes — 34 positional arguments, returns
+(out, softmax_lse, out_accum, softmax_lse_accum).
+
+Built: fp16 / bf16 / fp8 e4m3 inputs (fp8 -> bf16 output, :859), per-(batch, kv head) q/k/v descales (:1115-1146),
+dense and varlen (`cu_seqlens_*`, `seqused_*`), causal / sliding window / softcap, GQA.
+Accepted and rejected by message, like the reference does for compiled-out features (:1148-1165): k_new/v_new
+(append KV), qv, page_table, kv_batch_idx, leftpad_k, rotary_*, attention_chunk.  `scheduler_metadata`, `num_splits`,
+`pack_gqa`, `sm_margin` are performance hints and do not change results: ignored.
+"""
+import math
+from typing import Optional
+
+import torch
+
+from . import _dispatch, _lib
+
+_FP8 = getattr(torch, "float8_e4m3fn", None)
+
+
+def _check(cond, msg):
+    if not cond:
+        raise RuntimeError(msg)
+
+
+def fwd(q, k, v, k_new, v_new, qv, out, cu_seqlens_q, cu_seqlens_k, cu_seqlens_k_new, seqused_q, seqused_k,
+        max_seqlen_q, max_seqlen_k, page_table, kv_batch_idx, leftpad_k, rotary_cos, rotary_sin, seqlens_rotary,
+        q_descale, k_descale, v_descale, softmax_scale, is_causal, window_size_left, window_size_right,
+        attention_chunk, softcap, is_rotary_interleaved, scheduler_metadata, num_splits, pack_gqa, sm_margin):
+    _lib.load()
+    _check(q.dtype in (torch.float16, torch.bfloat16) or (_FP8 is not None and q.dtype == _FP8),
+           "FlashAttention only supports fp16, bf16, and fp8_e4m3 data type")  # hopper/flash_api.cpp:714-722
+    _check(k.dtype == q.dtype, "query and key must have the same dtype")
+    _check(v.dtype == q.dtype, "query and value must have the same dtype")
+    for t, n in ((q, "q"), (k, "k"), (v, "v")):
+        _check(t.is_cuda, f"{n} must be on CUDA")
+        _check(t.stride(-1) == 1, "Input tensor must have contiguous last dimension")
+    for x, n in ((k_new, "k_new"), (v_new, "v_new"), (qv, "qv"), (page_table, "page_table"),
+                 (kv_batch_idx, "kv_batch_idx"), (leftpad_k, "leftpad_k"), (rotary_cos, "rotary_cos"),
+                 (rotary_sin, "rotary_sin"), (seqlens_rotary, "seqlens_rotary"), (cu_seqlens_k_new, "cu_seqlens_k_new")):
+        _check(x is None, f"This flash attention build does not support {n}.")
+    _check(not attention_chunk, "This flash attention build does not support attention_chunk.")
+    is_fp8 = _FP8 is not None and q.dtype == _FP8
+    varlen_q = cu_seqlens_q is not None
+    varlen_k = cu_seqlens_k is not None
+    _check(varlen_q == varlen_k, "This flash attention build needs cu_seqlens_q and cu_seqlens_k together.")
+    if varlen_q:
+        _check(cu_seqlens_q.dtype == torch.int32 and cu_seqlens_k.dtype == torch.int32, "cu_seqlens must have dtype torch.int32")
+        _check(cu_seqlens_q.is_contiguous() and cu_seqlens_k.is_contiguous(), "cu_seqlens must be contiguous")
+        _check(max_seqlen_q is not None and max_seqlen_k is not None, "max_seqlen_q/k must be provided with cu_seqlens")
+        total_q, num_heads, head_size = q.shape
+        num_heads_k = k.shape[1]
+        batch_size = cu_seqlens_q.numel() - 1
+        seqlen_q, seqlen_k = int(max_seqlen_q), int(max_seqlen_k)
+    else:
+        batch_size, seqlen_q, num_heads, head_size = q.shape
+        seqlen_k, num_heads_k = k.shape[1], k.shape[2]
+        total_q = batch_size * seqlen_q
+    _check(batch_size > 0, "batch size must be positive")
+    _check(head_size <= 256, "FlashAttention forward only supports head dimension at most 256")
+    _check(head_size % (16 if is_fp8 else 8) == 0,
+           f"head_size should be a multiple of {16 if is_fp8 else 8}")  # :854-856
+    _check(num_heads % num_heads_k == 0, "Number of heads in key/value must divide number of heads in query")
+    for t, n in ((seqused_q, "seqused_q"), (seqused_k, "seqused_k")):
+        if t is not None:
+            _check(t.dtype == torch.int32 and t.is_contiguous() and t.numel() == batch_size, f"{n} must be int32 of shape (batch_size,)")
+    for t, n in ((q_descale, "q_descale"), (k_descale, "k_descale"), (v_descale, "v_descale")):
+        if t is not None:
+            _check(is_fp8, f"{n} is only supported with fp8 inputs")
+            _check(t.dtype == torch.float32 and tuple(t.shape) == (batch_size, num_heads_k), f"{n} must be fp32 (batch_size, num_heads_k)")
+    if softmax_scale is None:
+        softmax_scale = head_size ** (-0.5)
+    # causal/local normalisation, hopper/flash_api.cpp:796-805
+    if window_size_left >= seqlen_k - 1:
+        window_size_left = -1
+    if window_size_right >= seqlen_q - 1:
+        window_size_right = -1
+    if seqlen_q == 1 and window_size_left == -1 and window_size_right == -1:
+        is_causal = False  # causal=true is the same as causal=false in this case
+    if is_causal:
+        window_size_right = 0
+    out_dtype = torch.bfloat16 if is_fp8 else q.dtype  # :859
+    if out is not None:
+        _check(out.dtype == out_dtype, "For FP8 input, output must have dtype BF16" if is_fp8 else "Output must have the same dtype as inputs")
+        _check(out.is_cuda and out.stride(-1) == 1 and tuple(out.shape) == tuple(q.shape), "out must match q")
+    else:
+        out = torch.empty(q.shape, dtype=out_dtype, device=q.device)
+    with torch.cuda.device(q.device):
+        lse_shape = (num_heads, total_q) if varlen_q else (batch_size, num_heads, seqlen_q)
+        softmax_lse = torch.empty(lse_shape, dtype=torch.float32, device=q.device)
+        if seqlen_k > 0 and total_q > 0 and seqlen_q > 0:
+            qc, kc, vc = (x if _dispatch.aligned(x) else x.contiguous() for x in (q, k, v))
+            oc = out if _dispatch.aligned(out) else torch.empty_like(out)
+            _dispatch.launch(qc, kc, vc, oc, softmax_lse, varlen=varlen_q, batch=batch_size, max_seqlen_q=seqlen_q,
+                             max_seqlen_k=seqlen_k, softmax_scale=softmax_scale, causal=is_causal,
+                             window_left=window_size_left, window_right=window_size_right, softcap=softcap,
+                             cu_seqlens_q=cu_seqlens_q, cu_seqlens_k=cu_seqlens_k, seqused_q=seqused_q,
+                             seqused_k=seqused_k, q_descale=q_descale, k_descale=k_descale, v_descale=v_descale)
+            if oc is not out:
+                out.copy_(oc)
+        elif total_q > 0:
+            out.zero_()                    # hopper/flash_api.cpp:1190-1194
+            softmax_lse.fill_(math.inf)
+    return out, softmax_lse, None, None
+
+
+def bwd(*args, **kwargs):
+    raise RuntimeError("flash_attn_3.bwd: the backward pass is not built in this forward-only back-end")
+
+
+def fwd_combine(*args, **kwargs):
+    raise RuntimeError("flash_attn_3.fwd_combine: split-KV is not built in this back-end")
+
+
+def get_scheduler_metadata(*args, **kwargs):
+    raise RuntimeError("flash_attn_3.get_scheduler_metadata: not built (tile scheduling is done inside the kernel)")

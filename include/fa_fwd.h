@@ -9,7 +9,7 @@
  *   ------------------------------------------------------------  -----------------
  *   mha_fwd          csrc/flash_attn/flash_api.cpp:350-512        fa_fwd (dense)
  *   mha_varlen_fwd   csrc/flash_attn/flash_api.cpp:514-755        fa_fwd (cu_seqlens_* set)
- *   mha_fwd (FA3)    hopper/flash_api.cpp:672-1198                fa_fwd (+ seqused_*, descale)
+ *   mha_fwd (FA3)    hopper/flash_api.cpp:672-1198                fa_fwd (+ seqused_*, fp8 e4m3 + descale)
  *   set_params_fprop csrc/flash_attn/flash_api.cpp:26-159         fa_fwd_params (field for field)
  *   Flash_fwd_params csrc/flash_attn/src/flash.h:48-143,
  *                    hopper/flash.h:37-168                        fa_fwd_params
@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define FA_ABI_VERSION 1
+#define FA_ABI_VERSION 2
 
 /* element types of q/k/v (o has the same type; fp8 inputs produce bf16 o) */
 enum fa_dtype {
@@ -58,7 +58,8 @@ enum fa_status {
     FA_ERR_UNSUPPORTED = -7,       /* feature accepted by the ABI but not built (alibi, dropout, ...) */
     FA_ERR_LAUNCH = -8,            /* hipLaunchKernel failed */
     FA_ERR_BAD_ABI = -9,           /* params->abi_version / struct size mismatch */
-    FA_ERR_NO_DEVICE = -10         /* not a gfx950 device */
+    FA_ERR_NO_DEVICE = -10,        /* not a gfx950 device */
+    FA_ERR_WORKSPACE = -11         /* fp8 inputs need params->workspace of fa_fwd_workspace_size() bytes */
 };
 
 /*
@@ -116,12 +117,21 @@ typedef struct fa_fwd_params {
 
     /* performance hint, never changes results: 0 = library default */
     int32_t kernel_variant;
-    int32_t reserved0;
+    int32_t total_k;      /* varlen: rows of k/v (only needed for fp8 inputs: size of the expansion workspace) */
+
+    /* fp8 only: caller-provided scratch (the callee never allocates), 256-byte aligned, fa_fwd_workspace_size() bytes.
+     * The fp8 path expands q/k/v to bf16 (exact: every e4m3 value is a bf16 value) and runs the 16-bit mainloop with
+     * the descales folded into the softmax scale and the final normalisation. */
+    void *workspace;
+    uint64_t workspace_bytes;
 } fa_fwd_params;
 
 /* Validate and enqueue the forward on `stream` (a hipStream_t; NULL = default
  * stream).  Returns FA_OK or a negative fa_status; asynchronous. */
 int fa_fwd(const fa_fwd_params *params, void *stream);
+
+/* Scratch bytes fa_fwd needs in params->workspace for these params (0 for fp16/bf16 inputs; <0 = fa_status). */
+int64_t fa_fwd_workspace_size(const fa_fwd_params *params);
 
 /* Validation only (what mha_fwd's TORCH_CHECKs do); no device access. */
 int fa_fwd_validate(const fa_fwd_params *params);

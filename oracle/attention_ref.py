@@ -35,7 +35,8 @@ def local_mask(seqlen_q, seqlen_k, window_size=(-1, -1), query_padding_mask=None
 
 
 def attention_ref(q, k, v, query_padding_mask=None, key_padding_mask=None, attn_bias=None, causal=False,
-                  window_size=(-1, -1), softcap=0.0, upcast=True, reorder_ops=False, return_lse=False):
+                  window_size=(-1, -1), softcap=0.0, upcast=True, reorder_ops=False, return_lse=False,
+                  q_descale=None, k_descale=None, v_descale=None, intermediate_dtype=None):
     """Exact softmax attention.
 
     q: (b, sq, h, d); k, v: (b, sk, h_k, d) with h % h_k == 0 (kv head = q head // (h/h_k)).
@@ -51,6 +52,13 @@ def attention_ref(q, k, v, query_padding_mask=None, key_padding_mask=None, attn_
     dtype_og = q.dtype
     if upcast:
         q, k, v = q.float(), k.float(), v.float()
+    # fp8 descales, per (batch, kv head): hopper/test_util.py:272-279
+    if q_descale is not None:
+        q = (q.float() * q_descale.repeat_interleave(q.shape[2] // k.shape[2], dim=1)[:, None, :, None]).to(q.dtype)
+    if k_descale is not None:
+        k = (k.float() * k_descale[:, None, :, None]).to(k.dtype)
+    if v_descale is not None:
+        v = (v.float() * v_descale[:, None, :, None]).to(v.dtype)
     b, sq, h, d = q.shape
     sk = k.shape[1]
     g = h // k.shape[2]
@@ -76,7 +84,10 @@ def attention_ref(q, k, v, query_padding_mask=None, key_padding_mask=None, attn_
         attention = attention.masked_fill(torch.all(masked, dim=-1, keepdim=True), 0.0)
     if query_padding_mask is not None:
         attention = attention.masked_fill(~query_padding_mask.view(b, 1, sq, 1), 0.0)
-    out = torch.einsum("bhts,bshd->bthd", attention, v)
+    attention_pv = attention
+    if intermediate_dtype is not None:  # P rounded through e.g. e4m3 (hopper/test_util.py:343-344)
+        attention_pv = attention.to(intermediate_dtype).to(attention.dtype)
+    out = torch.einsum("bhts,bshd->bthd", attention_pv, v)
     if query_padding_mask is not None:
         out = out.masked_fill(~query_padding_mask.view(b, sq, 1, 1), 0.0)
     if key_padding_mask is not None:

@@ -12,11 +12,12 @@ _DT = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}
 
 
 def _case(dtype, b, sq, sk, h, hk, d, causal=False, window=(-1, -1), softcap=0.0, padding="none", seed=0,
-          q_scale=1.0, store_row_stride=1):
+          q_scale=1.0, store_row_stride=1, fp8=False):
     if store_row_stride == 1:  # keep fixtures small: store every n-th query row of the big cases
         store_row_stride = max(1, (b * sq * h * d) // 12288)
     return dict(dtype=dtype, b=b, sq=sq, sk=sk, h=h, hk=hk, d=d, causal=causal, window=tuple(window),
-                softcap=softcap, padding=padding, seed=seed, q_scale=q_scale, store_row_stride=store_row_stride)
+                softcap=softcap, padding=padding, seed=seed, q_scale=q_scale, store_row_stride=store_row_stride,
+                fp8=fp8)
 
 
 CASES = {
@@ -45,6 +46,10 @@ CASES = {
     # ragged batches (key / query padding)
     "bf16_padded_causal": _case("bf16", 3, 128, 217, 4, 2, 64, causal=True, padding="random", seed=16),
     "fp16_padded": _case("fp16", 3, 97, 97, 2, 2, 128, padding="random", seed=17),
+    # fp8 e4m3 storage (BASELINE config 5 in miniature): bf16 values rounded through e4m3 + per-(batch, kv head)
+    # descales rand*2, exactly how hopper/test_flash_attn.py:135-147 builds its fp8 inputs
+    "fp8_descale_gqa_d128": _case("bf16", 2, 160, 200, 4, 2, 128, seed=18, fp8=True),
+    "fp8_descale_causal_d64": _case("bf16", 2, 130, 130, 4, 4, 64, causal=True, seed=19, fp8=True),
 }
 
 
@@ -56,7 +61,18 @@ def make_inputs(c):
     k = torch.randn(c["b"], c["sk"], c["hk"], c["d"], generator=g, dtype=torch.float32)
     v = torch.randn(c["b"], c["sk"], c["hk"], c["d"], generator=g, dtype=torch.float32)
     q = q * c["q_scale"]
-    return q.to(dt), k.to(dt), v.to(dt)
+    q, k, v = q.to(dt), k.to(dt), v.to(dt)
+    if c.get("fp8"):  # values an e4m3 tensor can hold, kept in bf16 for the oracle (the kernel gets .to(float8_e4m3fn))
+        q, k, v = (t.to(torch.float8_e4m3fn).to(dt) for t in (q, k, v))
+    return q, k, v
+
+
+def make_descales(c):
+    """(q_descale, k_descale, v_descale), each (b, hk) fp32 = rand * 2, or (None, None, None)."""
+    if not c.get("fp8"):
+        return None, None, None
+    g = torch.Generator().manual_seed(3000 + c["seed"])
+    return tuple(torch.rand(c["b"], c["hk"], generator=g, dtype=torch.float32) * 2 for _ in range(3))
 
 
 def padding_masks(c):

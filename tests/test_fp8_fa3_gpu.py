@@ -1,0 +1,132 @@
+"""GPU parity tests of the FA3-shaped surface: fp8 e4m3 inputs with per-(batch, kv head) descales (BASELINE config 5)
+and the FA3 extras (seqused_q/k), with the reference's FA3 tolerance contract:
+    |out - out_ref|max <= rtol * |out_pt - out_ref|max + fwd_atol,  rtol = 2,
+    fwd_atol = 2 * |(out_ref + 0.3 - 0.3) - out_ref|max             (hopper/test_flash_attn.py:193-194, 223)
+where out_pt is the same math in bf16 with P rounded through e4m3 (:180)."""
+import math
+
+import pytest
+import torch
+
+from oracle import attention_ref as oracle
+from oracle.cases import CASES, checksum, make_descales, make_inputs
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+FP8 = torch.float8_e4m3fn
+
+
+def _fa3():
+    from flash_attention_annotated_amd import hopper_interface
+    return hopper_interface
+
+
+def _check(out, out_ref, out_pt, rtol=2):
+    err = (out.float().cpu() - out_ref.float()).abs().max().item()
+    fwd_atol = 2 * (out_ref.float() + 0.3 - 0.3 - out_ref.float()).abs().max().item()
+    bound = rtol * (out_pt.float() - out_ref.float()).abs().max().item() + fwd_atol
+    assert math.isfinite(err) and err <= bound, f"max err {err:.3e} > bound {bound:.3e}"
+
+
+@pytest.mark.parametrize("name", [n for n, c in CASES.items() if c.get("fp8")])
+def test_fp8_golden_cases(name, golden):
+    """HIP output for fp8 inputs vs the reference FA3 oracle's frozen outputs."""
+    fa3 = _fa3()
+    c, g = CASES[name], golden[name]
+    q, k, v = make_inputs(c)
+    assert abs(checksum(q) - g["input_checksum"][0].item()) < 1e-6
+    qd, kd, vd = make_descales(c)
+    out, lse = fa3.flash_attn_func(q.to(FP8).to(DEV), k.to(FP8).to(DEV), v.to(FP8).to(DEV), causal=c["causal"],
+                                   q_descale=qd.to(DEV), k_descale=kd.to(DEV), v_descale=vd.to(DEV),
+                                   return_attn_probs=True)
+    assert out.dtype == torch.bfloat16  # hopper/flash_api.cpp:859
+    st = c["store_row_stride"]
+    _check(out[:, ::st], g["out_ref_fp32"], g["out_pt"])
+    fin = torch.isfinite(g["lse"])
+    assert (lse.cpu()[:, :, ::st][fin] - g["lse"][fin]).abs().max().item() < 5e-3
+
+
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("mha_type", ["mha", "gqa", "mqa"])
+@pytest.mark.parametrize("sq,sk,d", [(113, 203, 128), (512, 512, 128), (384, 1024, 64), (1024, 1024, 128)])
+def test_fp8_output(sq, sk, d, mha_type, causal):
+    """hopper/test_flash_attn.py::test_flash_attn_output, fp8 branch (:135-194)."""
+    fa3 = _fa3()
+    torch.manual_seed(0)
+    b, h = 3, 6
+    hk = {"mha": 6, "gqa": 2, "mqa": 1}[mha_type]
+    q_ref = torch.randn(b, sq, h, d, dtype=torch.bfloat16).to(FP8).to(torch.bfloat16)
+    k_ref = torch.randn(b, sk, hk, d, dtype=torch.bfloat16).to(FP8).to(torch.bfloat16)
+    v_ref = torch.randn(b, sk, hk, d, dtype=torch.bfloat16).to(FP8).to(torch.bfloat16)
+    qd, kd, vd = [torch.rand(b, hk, dtype=torch.float32) * 2 for _ in range(3)]
+    out = fa3.flash_attn_func(q_ref.to(FP8).to(DEV), k_ref.to(FP8).to(DEV), v_ref.to(FP8).to(DEV), causal=causal,
+                              q_descale=qd.to(DEV), k_descale=kd.to(DEV), v_descale=vd.to(DEV))
+    kw = dict(causal=causal, q_descale=qd, k_descale=kd, v_descale=vd)
+    out_ref, _ = oracle.attention_ref(q_ref, k_ref, v_ref, **kw)
+    out_pt, _ = oracle.attention_ref(q_ref, k_ref, v_ref, **kw, upcast=False, reorder_ops=True, intermediate_dtype=FP8)
+    _check(out, out_ref, out_pt)
+
+
+def test_fp8_without_descales_equals_bf16_path():
+    """No descales: the fp8 path must equal the bf16 kernel run on the expanded values, bit for bit (the expansion
+    e4m3 -> bf16 is exact and everything downstream is the same kernel)."""
+    fa3 = _fa3()
+    torch.manual_seed(1)
+    q = torch.randn(2, 300, 4, 128, dtype=torch.bfloat16).to(FP8)
+    k = torch.randn(2, 333, 2, 128, dtype=torch.bfloat16).to(FP8)
+    v = torch.randn(2, 333, 2, 128, dtype=torch.bfloat16).to(FP8)
+    o8 = fa3.flash_attn_func(q.to(DEV), k.to(DEV), v.to(DEV), causal=True)
+    o16 = fa3.flash_attn_func(q.to(torch.bfloat16).to(DEV), k.to(torch.bfloat16).to(DEV), v.to(torch.bfloat16).to(DEV), causal=True)
+    assert torch.equal(o8, o16)
+
+
+def test_fp8_varlen_with_seqused():
+    """Ragged fp8 batch with "unused" tail tokens via seqused_q/k (hopper/test_flash_attn.py:388-433)."""
+    fa3 = _fa3()
+    torch.manual_seed(2)
+    lens_q, lens_k = [70, 128, 33], [90, 200, 64]
+    used_q, used_k = [64, 128, 20], [80, 150, 64]
+    h, hk, d = 4, 2, 128
+    cuq = torch.tensor([0, 70, 198, 231], dtype=torch.int32)
+    cuk = torch.tensor([0, 90, 290, 354], dtype=torch.int32)
+    q = torch.randn(231, h, d, dtype=torch.bfloat16).to(FP8).to(torch.bfloat16)
+    k = torch.randn(354, hk, d, dtype=torch.bfloat16).to(FP8).to(torch.bfloat16)
+    v = torch.randn(354, hk, d, dtype=torch.bfloat16).to(FP8).to(torch.bfloat16)
+    qd, kd, vd = [torch.rand(3, hk, dtype=torch.float32) * 2 for _ in range(3)]
+    out = fa3.flash_attn_varlen_func(q.to(FP8).to(DEV), k.to(FP8).to(DEV), v.to(FP8).to(DEV), cuq.to(DEV), cuk.to(DEV),
+                                     max(lens_q), max(lens_k), seqused_q=torch.tensor(used_q, dtype=torch.int32, device=DEV),
+                                     seqused_k=torch.tensor(used_k, dtype=torch.int32, device=DEV), causal=True,
+                                     q_descale=qd.to(DEV), k_descale=kd.to(DEV), v_descale=vd.to(DEV))
+    for i in range(3):
+        qs = q[cuq[i]:cuq[i] + used_q[i]][None]
+        ks = k[cuk[i]:cuk[i] + used_k[i]][None]
+        vs = v[cuk[i]:cuk[i] + used_k[i]][None]
+        kw = dict(causal=True, q_descale=qd[i:i + 1], k_descale=kd[i:i + 1], v_descale=vd[i:i + 1])
+        ref, _ = oracle.attention_ref(qs, ks, vs, **kw)
+        pt, _ = oracle.attention_ref(qs, ks, vs, **kw, upcast=False, reorder_ops=True, intermediate_dtype=FP8)
+        _check(out[cuq[i]:cuq[i] + used_q[i]][None], ref, pt)
+
+
+def test_fa3_bf16_matches_fa2_surface():
+    """Same kernel behind both surfaces."""
+    import flash_attention_annotated_amd as fa2
+    fa3 = _fa3()
+    torch.manual_seed(3)
+    q = torch.randn(2, 257, 4, 64, dtype=torch.bfloat16, device=DEV)
+    k = torch.randn(2, 300, 2, 64, dtype=torch.bfloat16, device=DEV)
+    v = torch.randn(2, 300, 2, 64, dtype=torch.bfloat16, device=DEV)
+    o3, lse3 = fa3.flash_attn_func(q, k, v, causal=True, return_attn_probs=True)
+    o2, lse2, _ = fa2.flash_attn_func(q, k, v, causal=True, return_attn_probs=True)
+    assert torch.equal(o3, o2) and torch.equal(lse3, lse2)
+
+
+def test_fa3_rejections():
+    fa3 = _fa3()
+    q = torch.randn(1, 16, 2, 64, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(RuntimeError, match="does not support qv"):
+        fa3.flash_attn_func(q, q, q, qv=q)
+    with pytest.raises(RuntimeError, match="attention_chunk"):
+        fa3.flash_attn_func(q, q, q, attention_chunk=8)
+    q8 = torch.randn(1, 16, 2, 72, dtype=torch.bfloat16, device=DEV).to(FP8)
+    with pytest.raises(RuntimeError, match="multiple of 16"):
+        fa3.flash_attn_func(q8, q8, q8)
