@@ -54,7 +54,7 @@ def _check_lse(lse, lse_ref, tol=2e-3):
         assert err <= tol, f"lse err {err:.3e}"
 
 
-@pytest.mark.parametrize("name", [n for n, c in CASES.items() if c["dtype"] != "fp32"])
+@pytest.mark.parametrize("name", [n for n, c in CASES.items() if c["dtype"] != "fp32" and not c.get("fp8")])
 def test_golden_cases(name, golden):
     """Every 16-bit golden case: HIP output vs the reference's frozen out_ref / out_pt."""
     fa = _api()
