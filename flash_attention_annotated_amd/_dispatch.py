@@ -26,7 +26,7 @@ def aligned(t):
 
 def launch(q, k, v, out, lse, *, varlen, batch, max_seqlen_q, max_seqlen_k, softmax_scale, causal, window_left,
            window_right, softcap, cu_seqlens_q=None, cu_seqlens_k=None, seqused_q=None, seqused_k=None,
-           q_descale=None, k_descale=None, v_descale=None):
+           q_descale=None, k_descale=None, v_descale=None, alibi_slopes=None):
     """q/k/v/out: dense (b, s, h, d) or packed (total, h, d) tensors on one GPU, last stride 1, aligned()."""
     lib = _lib.load()
     prm = _lib.new_params()
@@ -59,6 +59,9 @@ def launch(q, k, v, out, lse, *, varlen, batch, max_seqlen_q, max_seqlen_k, soft
         if t is not None:
             setattr(prm, f"{name}_descale_batch_stride", t.stride(0))
             setattr(prm, f"{name}_descale_head_stride", t.stride(1))
+    if alibi_slopes is not None:  # (h) or (b, h) fp32, last stride 1 (checked by the callers)
+        prm.alibi_slopes = ptr(alibi_slopes)
+        prm.alibi_slopes_batch_stride = alibi_slopes.stride(0) if alibi_slopes.dim() == 2 else 0
     workspace = None
     need = lib.fa_fwd_workspace_size(ctypes.byref(prm))
     if need < 0:
@@ -75,3 +78,46 @@ def launch(q, k, v, out, lse, *, varlen, batch, max_seqlen_q, max_seqlen_k, soft
     if workspace is not None:
         workspace.record_stream(torch.cuda.current_stream(q.device))
     return out, lse
+
+
+def launch_bwd(dout, q, k, v, out, lse, dq, dk, dv, softmax_d, *, varlen, batch, max_seqlen_q, max_seqlen_k,
+               softmax_scale, causal, window_left, window_right, softcap, cu_seqlens_q=None, cu_seqlens_k=None,
+               alibi_slopes=None, deterministic=False):
+    """All tensors dense (b, s, h, d) or packed (total, h, d), last stride 1, aligned(); softmax_d fp32
+    (b, h, row_len) / (h, row_len).  Enqueues fa_bwd (include/fa_bwd.h) on torch's current stream."""
+    lib = _lib.load()
+    prm = _lib.new_bwd_params()
+    prm.q, prm.k, prm.v, prm.o, prm.dout = ptr(q), ptr(k), ptr(v), ptr(out), ptr(dout)
+    prm.softmax_lse, prm.softmax_d = ptr(lse), ptr(softmax_d)
+    prm.dq, prm.dk, prm.dv = ptr(dq), ptr(dk), ptr(dv)
+    names = (("q", q), ("k", k), ("v", v), ("o", out), ("do", dout), ("dq", dq), ("dk", dk), ("dv", dv))
+    if varlen:
+        for name, t in names:
+            setattr(prm, f"{name}_batch_stride", 0)
+            setattr(prm, f"{name}_row_stride", t.stride(0))
+            setattr(prm, f"{name}_head_stride", t.stride(1))
+        prm.total_q, prm.total_k = q.shape[0], k.shape[0]
+        prm.h, prm.h_k, prm.d = q.shape[1], k.shape[1], q.shape[2]
+    else:
+        for name, t in names:
+            setattr(prm, f"{name}_batch_stride", t.stride(0))
+            setattr(prm, f"{name}_row_stride", t.stride(1))
+            setattr(prm, f"{name}_head_stride", t.stride(2))
+        prm.total_q = prm.total_k = 0
+        prm.h, prm.h_k, prm.d = q.shape[2], k.shape[2], q.shape[3]
+    prm.softmax_d_row_len = softmax_d.shape[-1]
+    prm.b, prm.seqlen_q, prm.seqlen_k = int(batch), int(max_seqlen_q), int(max_seqlen_k)
+    prm.dtype = _DT[q.dtype]
+    prm.cu_seqlens_q, prm.cu_seqlens_k = ptr(cu_seqlens_q), ptr(cu_seqlens_k)
+    prm.softmax_scale = float(softmax_scale)
+    prm.softcap = float(softcap)
+    prm.is_causal = int(bool(causal))
+    prm.window_size_left, prm.window_size_right = int(window_left), int(window_right)
+    if alibi_slopes is not None:
+        prm.alibi_slopes = ptr(alibi_slopes)
+        prm.alibi_slopes_batch_stride = alibi_slopes.stride(0) if alibi_slopes.dim() == 2 else 0
+    prm.deterministic = int(bool(deterministic))
+    stream = torch.cuda.current_stream(q.device).cuda_stream
+    st = lib.fa_bwd(ctypes.byref(prm), ctypes.c_void_p(stream))
+    if st != 0:
+        raise RuntimeError(f"fa_bwd failed ({st}): {_lib.strerror(st)}")

@@ -1,4 +1,4 @@
-"""ctypes binding of the C-ABI in include/fa_fwd.h (libfa_fwd_gfx950.so).
+"""ctypes binding of the C-ABI in include/fa_fwd.h and include/fa_bwd.h (libfa_fwd_gfx950.so).
 
 The shared library is the product: there is no Python/CPU fallback.  If it is
 missing or the GPU is absent, every compute entry point raises.
@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, LIB_NAME)
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
-FA_ABI_VERSION = 2
+FA_ABI_VERSION = 3
 FA_DTYPE_FP16, FA_DTYPE_BF16, FA_DTYPE_FP8_E4M3 = 0, 1, 2
 
 # every symbol include/fa_fwd.h declares (tests check the .so exports all of them)
@@ -27,6 +27,10 @@ EXPORTED_SYMBOLS = (
     "fa_abi_version",
     "fa_fwd_tile_shape",
     "fa_set_default_variant",
+    # include/fa_bwd.h
+    "fa_bwd",
+    "fa_bwd_validate",
+    "fa_bwd_params_size",
 )
 
 
@@ -83,14 +87,35 @@ class FaFwdParams(ctypes.Structure):
         ("total_k", ctypes.c_int32),
         ("workspace", ctypes.c_void_p),
         ("workspace_bytes", ctypes.c_uint64),
+        ("alibi_slopes", ctypes.c_void_p),
+        ("alibi_slopes_batch_stride", ctypes.c_int64),
     ]
+
+
+class FaBwdParams(ctypes.Structure):
+    """Field-for-field mirror of `struct fa_bwd_params` (include/fa_bwd.h)."""
+
+    _fields_ = (
+        [("abi_version", ctypes.c_uint32), ("struct_size", ctypes.c_uint32)]
+        + [(n, ctypes.c_void_p) for n in ("q", "k", "v", "o", "dout", "softmax_lse", "dq", "dk", "dv", "softmax_d")]
+        + [(f"{t}_{s}_stride", ctypes.c_int64) for t in ("q", "k", "v", "o", "do", "dq", "dk", "dv")
+           for s in ("batch", "row", "head")]
+        + [("softmax_d_row_len", ctypes.c_int64)]
+        + [(n, ctypes.c_int32) for n in ("b", "seqlen_q", "seqlen_k", "h", "h_k", "d", "total_q", "total_k", "dtype")]
+        + [("cu_seqlens_q", ctypes.c_void_p), ("cu_seqlens_k", ctypes.c_void_p)]
+        + [("softmax_scale", ctypes.c_float), ("softcap", ctypes.c_float)]
+        + [("is_causal", ctypes.c_int32), ("window_size_left", ctypes.c_int32), ("window_size_right", ctypes.c_int32)]
+        + [("alibi_slopes", ctypes.c_void_p), ("alibi_slopes_batch_stride", ctypes.c_int64)]
+        + [("deterministic", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+    )
 
 
 def build(force=False, verbose=False):
     """Compile csrc/ for gfx950 into the in-tree shared library (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, "fa_fwd_api.hip")]
+    srcs = [os.path.join(CSRC, "fa_fwd_api.hip"), os.path.join(CSRC, "fa_bwd_api.hip")]
     deps = srcs + [os.path.join(CSRC, "fa_fwd_kernel.h"), os.path.join(CSRC, "fa_fwd_kernel_w64.h"),
-                   os.path.join(INCLUDE, "fa_fwd.h")]
+                   os.path.join(CSRC, "fa_bwd_kernel.h"), os.path.join(INCLUDE, "fa_fwd.h"),
+                   os.path.join(INCLUDE, "fa_bwd.h")]
     if not force and os.path.exists(LIB_PATH):
         if os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps):
             return LIB_PATH
@@ -135,6 +160,14 @@ def load():
     lib.fa_fwd_tile_shape.restype = ctypes.c_int
     lib.fa_set_default_variant.argtypes = [ctypes.c_int32]
     lib.fa_set_default_variant.restype = None
+    lib.fa_bwd.argtypes = [ctypes.POINTER(FaBwdParams), ctypes.c_void_p]
+    lib.fa_bwd.restype = ctypes.c_int
+    lib.fa_bwd_validate.argtypes = [ctypes.POINTER(FaBwdParams)]
+    lib.fa_bwd_validate.restype = ctypes.c_int
+    lib.fa_bwd_params_size.argtypes = []
+    lib.fa_bwd_params_size.restype = ctypes.c_uint32
+    if lib.fa_bwd_params_size() != ctypes.sizeof(FaBwdParams):
+        raise RuntimeError("fa_bwd_params layout mismatch between include/fa_bwd.h and _lib.FaBwdParams")
     if lib.fa_fwd_params_size() != ctypes.sizeof(FaFwdParams):
         raise RuntimeError("fa_fwd_params layout mismatch between include/fa_fwd.h and _lib.FaFwdParams")
     if lib.fa_abi_version() != FA_ABI_VERSION:
@@ -147,6 +180,13 @@ def load():
 
 def strerror(status):
     return load().fa_strerror(status).decode()
+
+
+def new_bwd_params():
+    p = FaBwdParams()
+    p.abi_version = FA_ABI_VERSION
+    p.struct_size = ctypes.sizeof(FaBwdParams)
+    return p
 
 
 def new_params():

@@ -1,0 +1,658 @@
+// fa_bwd_kernel.h — gfx950 (CDNA4) FlashAttention backward, hand-written HIP.
+//
+// Roles re-derived for MI355X (not translated) from the reference's backward:
+//   preprocess  csrc/flash_attn/src/flash_bwd_preprocess_kernel.h:60-127 (dot(dO, O))          -> bwd_dot_kernel
+//   main loop   csrc/flash_attn/src/flash_bwd_kernel.h:80-830 (compute_dq_dk_dv_1colblock)       -> bwd_dkdv_kernel
+//               + dQ accumulated through atomics / dq_accum and convert_dQ (:flash_bwd_preprocess_kernel.h:232-)
+//                                                                                               -> bwd_dq_kernel
+//
+// With  S = scale * Q K^T (+ softcap, + ALiBi, masked),  P = exp(S - LSE),  D_i = sum_d dO_id O_id:
+//   dV = P^T dO,   dP = dO V^T,   dS = P o (dP - D) [o (1 - tanh^2) under softcap],   dQ = scale dS K,   dK = scale dS^T Q
+//
+// Design.  Two MFMA kernels so that every output element has ONE producer (no atomics, bit-reproducible):
+//   * dK/dV: workgroup = 128 keys of one (batch, kv head); wave w owns keys 32w..32w+31 and keeps their K and V
+//     fragments in registers for the whole kernel (B operands).  Q and dO tiles (64 rows) of every query head of
+//     the GQA group stream through double-buffered, XOR-swizzled LDS.  S = Q K^T and dP = dO V^T land with the KEY
+//     on the lane and the query row in the accumulator registers, so P and dS, rounded to 16 bit, ARE the B operands
+//     of  dV^T += dO^T P  and  dK^T += Q^T dS  (same register trick as the forward); the transposed A operands
+//     (dO^T, Q^T) come from the row-major LDS tiles through ds_read_b64_tr_b16.  dK/dV of a GQA group are summed
+//     in fp32 registers (the reference sums 16-bit per-head copies afterwards, flash_api.cpp:964-968).
+//   * dQ: the forward's shape -- workgroup = 128 query rows, wave = 32 rows, Q and dO fragments in registers,
+//     K/V tiles (64 keys) through LDS; S^T = K Q^T and dP^T = V dO^T have the query on the lane, so LSE and D are
+//     per-lane scalars and dS^T is directly the B operand of  dQ^T += K^T dS^T  (K^T through transposing reads of
+//     the same K tile).
+#pragma once
+
+#include "fa_fwd_kernel.h"
+
+namespace fa {
+
+struct BParams {
+    const void *q, *k, *v, *o, *dout;
+    const float *lse;
+    void *dq, *dk, *dv;
+    float *dsum;
+    const int32_t *cu_seqlens_q, *cu_seqlens_k;
+    int64_t q_batch_stride, q_row_stride, q_head_stride;
+    int64_t k_batch_stride, k_row_stride, k_head_stride;
+    int64_t v_batch_stride, v_row_stride, v_head_stride;
+    int64_t o_batch_stride, o_row_stride, o_head_stride;
+    int64_t do_batch_stride, do_row_stride, do_head_stride;
+    int64_t dq_batch_stride, dq_row_stride, dq_head_stride;
+    int64_t dk_batch_stride, dk_row_stride, dk_head_stride;
+    int64_t dv_batch_stride, dv_row_stride, dv_head_stride;
+    int64_t dsum_row_len;
+    int32_t b, seqlen_q, seqlen_k, h, h_k, d, total_q;
+    int32_t h_ratio;
+    int32_t num_blocks;    // blocks per (batch, head): key blocks (dK/dV) or query blocks (dQ)
+    int32_t num_tiles;     // work list length
+    int32_t grid;          // workgroups launched (multiple of 8 units, see decode_block)
+    int32_t window_left, window_right;
+    float scale_log2;      // log2(e) * (softmax_scale, or the softcap value under softcap)
+    float softcap_pre;     // softmax_scale / softcap (0 when softcap is off)
+    float out_scale;       // softmax_scale: the factor of dQ and dK
+    const float *alibi;
+    int32_t alibi_bs;
+};
+
+// Work list (batch, head, block) cut into units = all blocks of one (batch, head) (they stream the same operands);
+// units are dealt round-robin to the 8 XCDs exactly like decode_tile() does for the forward.
+__device__ __forceinline__ bool decode_block(const BParams &p, int &block, int &head, int &batch, int heads) {
+    const int wg = blockIdx.x;
+    const int xcd = wg & 7, slot = wg >> 3;
+    const int unit = (slot / p.num_blocks) * 8 + xcd;
+    const int tile = unit * p.num_blocks + slot % p.num_blocks;
+    if (tile >= p.num_tiles) return false;
+    const int bh = tile / p.num_blocks;
+    block = p.num_blocks - 1 - tile % p.num_blocks;
+    batch = bh / heads;
+    head = bh % heads;
+    return true;
+}
+
+struct BSeq {
+    int sq, sk;
+    int64_t q_base, k_base, v_base, o_base, do_base, dq_base, dk_base, dv_base;
+    int64_t stat_base;  // + head * stat_head_stride + row : index into softmax_lse
+    int64_t dsum_base;  // same for softmax_d
+    int64_t lse_hs, dsum_hs;
+};
+__device__ __forceinline__ BSeq bwd_seq(const BParams &p, int batch) {
+    BSeq s;
+    if (p.cu_seqlens_q) {
+        const int q0 = p.cu_seqlens_q[batch], k0 = p.cu_seqlens_k[batch];
+        s.sq = p.cu_seqlens_q[batch + 1] - q0;
+        s.sk = p.cu_seqlens_k[batch + 1] - k0;
+        s.q_base = (int64_t)q0 * p.q_row_stride;
+        s.o_base = (int64_t)q0 * p.o_row_stride;
+        s.do_base = (int64_t)q0 * p.do_row_stride;
+        s.dq_base = (int64_t)q0 * p.dq_row_stride;
+        s.k_base = (int64_t)k0 * p.k_row_stride;
+        s.v_base = (int64_t)k0 * p.v_row_stride;
+        s.dk_base = (int64_t)k0 * p.dk_row_stride;
+        s.dv_base = (int64_t)k0 * p.dv_row_stride;
+        s.stat_base = q0;
+        s.dsum_base = q0;
+        s.lse_hs = p.total_q;
+        s.dsum_hs = p.dsum_row_len;
+    } else {
+        s.sq = p.seqlen_q;
+        s.sk = p.seqlen_k;
+        s.q_base = (int64_t)batch * p.q_batch_stride;
+        s.o_base = (int64_t)batch * p.o_batch_stride;
+        s.do_base = (int64_t)batch * p.do_batch_stride;
+        s.dq_base = (int64_t)batch * p.dq_batch_stride;
+        s.k_base = (int64_t)batch * p.k_batch_stride;
+        s.v_base = (int64_t)batch * p.v_batch_stride;
+        s.dk_base = (int64_t)batch * p.dk_batch_stride;
+        s.dv_base = (int64_t)batch * p.dv_batch_stride;
+        s.stat_base = (int64_t)batch * p.h * p.seqlen_q;
+        s.dsum_base = (int64_t)batch * p.h * p.dsum_row_len;
+        s.lse_hs = p.seqlen_q;
+        s.dsum_hs = p.dsum_row_len;
+    }
+    return s;
+}
+
+// two packed 16-bit values -> fp32 (plain bit operations for bf16)
+template <typename T>
+__device__ __forceinline__ void unpack2(uint32_t w, float &lo, float &hi) {
+    if constexpr (sizeof(T) == 2 && __is_same(T, __bf16)) {
+        lo = __uint_as_float(w << 16);
+        hi = __uint_as_float(w & 0xffff0000u);
+    } else {
+        lo = (float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xffffu));
+        hi = (float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16));
+    }
+}
+
+// ---- D = rowsum(dO * O), fp32.  One thread per (row, head), 16-byte loads.  HBM-bound, ~2 % of the backward. -------
+template <typename T>
+__global__ __launch_bounds__(256) void bwd_dot_kernel(const BParams p) {
+    const int64_t rows_total = p.cu_seqlens_q ? (int64_t)p.total_q : (int64_t)p.b * p.seqlen_q;
+    const int64_t items = rows_total * p.h;
+    for (int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x; item < items; item += (int64_t)gridDim.x * 256) {
+        const int head = (int)(item % p.h);
+        const int64_t row = item / p.h;
+        int64_t o_off, do_off, d_off;
+        if (p.cu_seqlens_q) {
+            o_off = row * p.o_row_stride;
+            do_off = row * p.do_row_stride;
+            d_off = (int64_t)head * p.dsum_row_len + row;
+        } else {
+            const int64_t bb = row / p.seqlen_q, rr = row % p.seqlen_q;
+            o_off = bb * p.o_batch_stride + rr * p.o_row_stride;
+            do_off = bb * p.do_batch_stride + rr * p.do_row_stride;
+            d_off = (bb * p.h + head) * p.dsum_row_len + rr;
+        }
+        const T *op = (const T *)p.o + o_off + (int64_t)head * p.o_head_stride;
+        const T *gp = (const T *)p.dout + do_off + (int64_t)head * p.do_head_stride;
+        float acc = 0.f;
+        for (int c = 0; c < p.d; c += 8) {
+            const u32x4 a = *(const u32x4 *)(op + c);
+            const u32x4 g = *(const u32x4 *)(gp + c);
+            const uint32_t aw[4] = {a[0], a[1], a[2], a[3]}, gw[4] = {g[0], g[1], g[2], g[3]};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float x0, x1, y0, y1;
+                unpack2<T>(aw[j], x0, x1);
+                unpack2<T>(gw[j], y0, y1);
+                acc += x0 * y0 + x1 * y1;
+            }
+        }
+        p.dsum[d_off] = acc;
+    }
+}
+
+// Elementwise core shared by both kernels: from raw score x and dP to (P, dS) for one (query i, key j).
+template <bool SOFTCAP>
+__device__ __forceinline__ void bwd_point(const BParams &p, float x, float dp, float lse2, float dsum, float alibi2,
+                                          int rel /* i + sk - sq - j */, bool visible, float &pv, float &ds) {
+    float t = 0.f, sl;
+    if constexpr (SOFTCAP) {
+        t = fast_tanh(x * p.softcap_pre);
+        sl = t * p.scale_log2;
+    } else {
+        sl = x * p.scale_log2;
+    }
+    if (p.alibi) sl -= alibi2 * fabsf((float)rel);
+    pv = visible ? __builtin_amdgcn_exp2f(sl - lse2) : 0.f;
+    ds = pv * (dp - dsum);
+    if constexpr (SOFTCAP) ds *= (1.f - t * t);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// dK / dV
+// ------------------------------------------------------------------------------------------------------------------
+template <typename T, int D, bool SOFTCAP>
+__global__ __launch_bounds__(256, 1) void bwd_dkdv_kernel(const BParams p) {
+    constexpr int NT = 256;
+    constexpr int BLOCK_K = 128;               // keys per workgroup (32 per wave)
+    constexpr int BM = 64;                     // query rows per streamed tile
+    constexpr int KSTEPS = D / 16;
+    constexpr int DBLOCKS = D / 32;
+    constexpr int CH_PER_ROW = D / 8;
+    constexpr int TILE_BYTES = BM * D * 2;
+    constexpr int CHUNKS = BM * CH_PER_ROW;
+    constexpr int LD_PER_THREAD = CHUNKS / NT;
+    static_assert(CHUNKS % NT == 0, "tile must divide over the workgroup");
+    constexpr int O_ROW_BYTES = D * 2 + 16;
+    constexpr float LOG2E = 1.4426950408889634f;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // [Q0 | Q1 | dO0 | dO1 | lse[2][64] | dsum[2][64]]; the epilogue reuses the front as 4 x [32][O_ROW_BYTES]
+    float *lse_s = (float *)(smem + 4 * TILE_BYTES);
+    float *dsum_s = lse_s + 2 * BM;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int i16 = lane & 15, g1 = (lane >> 4) & 1;
+
+    int n_block, kv_head, batch;
+    if (!decode_block(p, n_block, kv_head, batch, p.h_k)) return;
+    const BSeq sq_ = bwd_seq(p, batch);
+    const int sq = sq_.sq, sk = sq_.sk;
+    const int n0 = n_block * BLOCK_K;
+    if (n0 >= sk) return;
+    const int shift = sk - sq;
+
+    // query rows that can see any key of this block
+    const int last_key = min(sk, n0 + BLOCK_K) - 1;
+    int row_lo = 0, row_hi = sq;
+    if (p.window_right >= 0) row_lo = max(0, n0 - shift - p.window_right);
+    if (p.window_left >= 0) row_hi = min(sq, last_key - shift + p.window_left + 1);
+    const int m_min = row_lo / BM;
+    const int m_max = row_hi > row_lo ? (row_hi + BM - 1) / BM : m_min;
+    const int num_m = m_max - m_min;
+    const int total_it = num_m * p.h_ratio;
+
+    const int key_w0 = n0 + wave * 32;
+    const int my_key = key_w0 + r;
+
+    // ---- K, V fragments of this wave's 32 keys: B operands of S = Q K^T and dP = dO V^T ---------------------
+    const T *kp = (const T *)p.k + sq_.k_base + (int64_t)kv_head * p.k_head_stride;
+    const T *vp = (const T *)p.v + sq_.v_base + (int64_t)kv_head * p.v_head_stride;
+    u32x4 kf[KSTEPS], vf[KSTEPS];
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+        const int d0 = ks * 16 + hh * 8;
+        u32x4 a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
+        if (my_key < sk && d0 < p.d) {
+            a = *(const u32x4 *)(kp + (int64_t)my_key * p.k_row_stride + d0);
+            b = *(const u32x4 *)(vp + (int64_t)my_key * p.v_row_stride + d0);
+        }
+        kf[ks] = a;
+        vf[ks] = b;
+    }
+
+    f32x16 dk_acc[DBLOCKS], dv_acc[DBLOCKS];
+#pragma unroll
+    for (int db = 0; db < DBLOCKS; ++db)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { dk_acc[db][i] = 0.f; dv_acc[db][i] = 0.f; }
+
+    // ---- Q / dO tile staging (register-staged, rows clamped into the sequence: clamped rows are masked) ---------
+    u32x4 qreg[LD_PER_THREAD], greg[LD_PER_THREAD];
+    float stat_reg = 0.f;
+    int ld_row[LD_PER_THREAD], ld_col[LD_PER_THREAD];
+#pragma unroll
+    for (int i = 0; i < LD_PER_THREAD; ++i) {
+        const int c = tid + i * NT;
+        ld_row[i] = c / CH_PER_ROW;
+        const int ch = c % CH_PER_ROW;
+        ld_col[i] = (ch * 8 < p.d) ? ch * 8 : 0;
+    }
+    auto tile_head = [&](int it) { return kv_head * p.h_ratio + it / num_m; };
+    auto tile_row0 = [&](int it) { return (m_min + it % num_m) * BM; };
+    auto load_tile = [&](int it) {
+        const int head = tile_head(it), row0 = tile_row0(it);
+        const T *qp = (const T *)p.q + sq_.q_base + (int64_t)head * p.q_head_stride;
+        const T *gp = (const T *)p.dout + sq_.do_base + (int64_t)head * p.do_head_stride;
+#pragma unroll
+        for (int i = 0; i < LD_PER_THREAD; ++i) {
+            const int row = min(row0 + ld_row[i], sq - 1);
+            qreg[i] = *(const u32x4 *)(qp + (int64_t)row * p.q_row_stride + ld_col[i]);
+            greg[i] = *(const u32x4 *)(gp + (int64_t)row * p.do_row_stride + ld_col[i]);
+        }
+        if (tid < 2 * BM) {  // threads 0..63: LSE (log2 units), 64..127: D
+            const int row = min(row0 + (tid & (BM - 1)), sq - 1);
+            if (tid < BM) {
+                const float l = p.lse[sq_.stat_base + (int64_t)head * sq_.lse_hs + row];
+                stat_reg = l * LOG2E;  // +inf (row without keys) stays +inf: P = exp2(-inf) = 0
+            } else {
+                stat_reg = p.dsum[sq_.dsum_base + (int64_t)head * sq_.dsum_hs + row];
+            }
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < LD_PER_THREAD; ++i) {
+            const int c = tid + i * NT;
+            const int off = lds_off<D>(c / CH_PER_ROW, c % CH_PER_ROW);
+            *(u32x4 *)(smem + buf * TILE_BYTES + off) = qreg[i];
+            *(u32x4 *)(smem + (2 + buf) * TILE_BYTES + off) = greg[i];
+        }
+        if (tid < BM) lse_s[buf * BM + tid] = stat_reg;
+        else if (tid < 2 * BM) dsum_s[buf * BM + tid - BM] = stat_reg;
+    };
+
+    if (total_it > 0) {
+        load_tile(0);
+        store_tile(0);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see fa_fwd_kernel.h
+    __syncthreads();
+
+    for (int it = 0; it < total_it; ++it) {
+        const int cur = it & 1;
+        const bool has_next = it + 1 < total_it;
+        if (has_next) load_tile(it + 1);
+
+        const int head = tile_head(it), row0 = tile_row0(it);
+        const float alibi2 = p.alibi ? p.alibi[(int64_t)batch * p.alibi_bs + head] * LOG2E : 0.f;
+        const char *qbuf = smem + cur * TILE_BYTES;
+        const char *gbuf = smem + (2 + cur) * TILE_BYTES;
+
+        // wave-level skip: no (row, key) pair of this tile x this wave's keys is visible
+        bool skip = key_w0 >= sk;
+        if (p.window_right >= 0) skip = skip || (key_w0 > row0 + BM - 1 + shift + p.window_right);
+        if (p.window_left >= 0) skip = skip || (key_w0 + 31 < row0 + shift - p.window_left);
+
+        if (!skip) {
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                // ---- S = Q K^T and dP = dO V^T for 32 query rows x this wave's 32 keys -------------------
+                f32x16 s, dp;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+#pragma unroll
+                for (int ks = 0; ks < KSTEPS; ++ks) {
+                    const int off = lds_off<D>(32 * rb + r, 2 * ks + hh);
+                    const u32x4 qa = *(const u32x4 *)(qbuf + off);
+                    const u32x4 ga = *(const u32x4 *)(gbuf + off);
+                    s = Elem<T>::mma(qa, kf[ks], s);
+                    dp = Elem<T>::mma(ga, vf[ks], dp);
+                }
+                // ---- P and dS: key on the lane, query row = register ----------------------------------
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int rbase = 32 * rb + 8 * g4 + 4 * hh;
+                    const float4 l4 = *(const float4 *)(lse_s + cur * BM + rbase);
+                    const float4 d4 = *(const float4 *)(dsum_s + cur * BM + rbase);
+                    const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dsv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int i = 4 * g4 + e;
+                        const int qi = row0 + rbase + e;
+                        const int rel = qi + shift - my_key;
+                        bool vis = (my_key < sk) && (qi < sq);
+                        if (p.window_right >= 0) vis = vis && (rel + p.window_right >= 0);
+                        if (p.window_left >= 0) vis = vis && (rel <= p.window_left);
+                        float pv, ds;
+                        bwd_point<SOFTCAP>(p, s[i], dp[i], lv[e], dsv[e], alibi2, rel, vis, pv, ds);
+                        s[i] = pv;
+                        dp[i] = ds;
+                    }
+                }
+                u32x4 pf[2], dsf[2];
+#pragma unroll
+                for (int st = 0; st < 2; ++st)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        pf[st][j] = Elem<T>::pack2(s[8 * st + 2 * j], s[8 * st + 2 * j + 1]);
+                        dsf[st][j] = Elem<T>::pack2(dp[8 * st + 2 * j], dp[8 * st + 2 * j + 1]);
+                    }
+                // ---- dV^T += dO^T P,  dK^T += Q^T dS  (A operands through transposing LDS reads) ----------
+                // element j of lane half hh of 16-row step st is query row 16st + 8(j>>2) + 4hh + (j&3)
+#pragma unroll
+                for (int db = 0; db < DBLOCKS; ++db) {
+#pragma unroll
+                    for (int st = 0; st < 2; ++st) {
+                        u32x4 gt, qt;
+#pragma unroll
+                        for (int j2 = 0; j2 < 2; ++j2) {
+                            const int row = 32 * rb + 16 * st + 8 * j2 + 4 * hh + (i16 >> 2);
+                            const int ch = db * 4 + 2 * g1 + ((i16 >> 1) & 1);
+                            const int off = lds_off<D>(row, ch) + 8 * (i16 & 1);
+                            const u32x2 a = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                (__attribute__((address_space(3))) s16x4 *)(gbuf + off)));
+                            const u32x2 b = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                (__attribute__((address_space(3))) s16x4 *)(qbuf + off)));
+                            gt[2 * j2] = a[0]; gt[2 * j2 + 1] = a[1];
+                            qt[2 * j2] = b[0]; qt[2 * j2 + 1] = b[1];
+                        }
+                        dv_acc[db] = Elem<T>::mma(gt, pf[st], dv_acc[db]);
+                        dk_acc[db] = Elem<T>::mma(qt, dsf[st], dk_acc[db]);
+                    }
+                }
+            }
+        }
+
+        if (has_next) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: dK^T / dV^T registers (lane = key, registers = head dim) -> LDS -> coalesced rows ------------
+    T *dkp = (T *)p.dk + sq_.dk_base + (int64_t)kv_head * p.dk_head_stride;
+    T *dvp = (T *)p.dv + sq_.dv_base + (int64_t)kv_head * p.dv_head_stride;
+    char *obuf = smem + wave * (32 * O_ROW_BYTES);
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        const float f = which == 0 ? p.out_scale : 1.f;
+#pragma unroll
+        for (int db = 0; db < DBLOCKS; ++db)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x16 &acc = which == 0 ? dk_acc[db] : dv_acc[db];
+                u32x2 w;
+                w[0] = Elem<T>::pack2(acc[4 * g4] * f, acc[4 * g4 + 1] * f);
+                w[1] = Elem<T>::pack2(acc[4 * g4 + 2] * f, acc[4 * g4 + 3] * f);
+                *(u32x2 *)(obuf + r * O_ROW_BYTES + (db * 32 + 8 * g4 + 4 * hh) * 2) = w;
+            }
+        __syncthreads();
+        T *dst = which == 0 ? dkp : dvp;
+        const int64_t rs = which == 0 ? p.dk_row_stride : p.dv_row_stride;
+#pragma unroll
+        for (int i = 0; i < (32 * CH_PER_ROW) / 64; ++i) {
+            const int c = lane + i * 64;
+            const int row = c / CH_PER_ROW, ch = c % CH_PER_ROW;
+            if (key_w0 + row < sk && ch * 8 < p.d) {
+                const u32x4 val = *(const u32x4 *)(obuf + row * O_ROW_BYTES + ch * 16);
+                *(u32x4 *)(dst + (int64_t)(key_w0 + row) * rs + ch * 8) = val;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int D>
+constexpr int smem_bytes_dkdv() {
+    constexpr int tiles = 4 * 64 * D * 2 + 4 * 64 * 4;
+    constexpr int o = 4 * 32 * (D * 2 + 16);
+    return tiles > o ? tiles : o;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// dQ
+// ------------------------------------------------------------------------------------------------------------------
+template <typename T, int D, bool SOFTCAP>
+__global__ __launch_bounds__(256, 1) void bwd_dq_kernel(const BParams p) {
+    constexpr int NT = 256;
+    constexpr int BLOCK_M = 128;
+    constexpr int KSTEPS = D / 16;
+    constexpr int DBLOCKS = D / 32;
+    constexpr int CH_PER_ROW = D / 8;
+    constexpr int TILE_BYTES = BLOCK_N * D * 2;
+    constexpr int CHUNKS = BLOCK_N * CH_PER_ROW;
+    constexpr int LD_PER_THREAD = CHUNKS / NT;
+    static_assert(CHUNKS % NT == 0, "tile must divide over the workgroup");
+    constexpr int O_ROW_BYTES = D * 2 + 16;
+    constexpr float LOG2E = 1.4426950408889634f;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [K0 | K1 | V0 | V1]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int i16 = lane & 15, g1 = (lane >> 4) & 1;
+
+    int m_block, head, batch;
+    if (!decode_block(p, m_block, head, batch, p.h)) return;
+    const int kv_head = head / p.h_ratio;
+    const BSeq sq_ = bwd_seq(p, batch);
+    const int sq = sq_.sq, sk = sq_.sk;
+    const int row_lo = m_block * BLOCK_M;
+    if (row_lo >= sq) return;
+    const int shift = sk - sq;
+    const int row_hi = min(sq, row_lo + BLOCK_M);
+    int key_hi = sk, key_lo = 0;
+    if (p.window_right >= 0) key_hi = min(sk, row_hi + shift + p.window_right);
+    if (p.window_left >= 0) key_lo = max(0, row_lo + shift - p.window_left);
+    const int n_min = key_lo / BLOCK_N;
+    const int n_max = key_hi > 0 ? (key_hi + BLOCK_N - 1) / BLOCK_N : 0;
+
+    const int wrow = row_lo + wave * 32;
+    const int my_row = wrow + r;
+    const bool wave_active = wrow < sq;
+
+    const T *qp = (const T *)p.q + sq_.q_base + (int64_t)head * p.q_head_stride;
+    const T *gp = (const T *)p.dout + sq_.do_base + (int64_t)head * p.do_head_stride;
+    const T *kp = (const T *)p.k + sq_.k_base + (int64_t)kv_head * p.k_head_stride;
+    const T *vp = (const T *)p.v + sq_.v_base + (int64_t)kv_head * p.v_head_stride;
+
+    // ---- Q, dO fragments (B operands), LSE and D of this lane's row -----------------------------------------
+    u32x4 qf[KSTEPS], gf[KSTEPS];
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+        const int d0 = ks * 16 + hh * 8;
+        u32x4 a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
+        if (my_row < sq && d0 < p.d) {
+            a = *(const u32x4 *)(qp + (int64_t)my_row * p.q_row_stride + d0);
+            b = *(const u32x4 *)(gp + (int64_t)my_row * p.do_row_stride + d0);
+        }
+        qf[ks] = a;
+        gf[ks] = b;
+    }
+    float lse2 = INFINITY, dsum = 0.f;
+    if (my_row < sq) {
+        lse2 = p.lse[sq_.stat_base + (int64_t)head * sq_.lse_hs + my_row] * LOG2E;
+        dsum = p.dsum[sq_.dsum_base + (int64_t)head * sq_.dsum_hs + my_row];
+    }
+    const float alibi2 = p.alibi ? p.alibi[(int64_t)batch * p.alibi_bs + head] * LOG2E : 0.f;
+
+    f32x16 dq_acc[DBLOCKS];
+#pragma unroll
+    for (int db = 0; db < DBLOCKS; ++db)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dq_acc[db][i] = 0.f;
+
+    // ---- K/V staging (as the forward: clamped rows, register staged) -------------------------------------------
+    u32x4 kreg[LD_PER_THREAD], vreg[LD_PER_THREAD];
+    int ld_row[LD_PER_THREAD], ld_col[LD_PER_THREAD];
+#pragma unroll
+    for (int i = 0; i < LD_PER_THREAD; ++i) {
+        const int c = tid + i * NT;
+        ld_row[i] = c / CH_PER_ROW;
+        const int ch = c % CH_PER_ROW;
+        ld_col[i] = (ch * 8 < p.d) ? ch * 8 : 0;
+    }
+    auto load_tile = [&](int n) {
+        const int k0 = n * BLOCK_N;
+#pragma unroll
+        for (int i = 0; i < LD_PER_THREAD; ++i) {
+            const int row = min(k0 + ld_row[i], sk - 1);
+            kreg[i] = *(const u32x4 *)(kp + (int64_t)row * p.k_row_stride + ld_col[i]);
+            vreg[i] = *(const u32x4 *)(vp + (int64_t)row * p.v_row_stride + ld_col[i]);
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < LD_PER_THREAD; ++i) {
+            const int c = tid + i * NT;
+            const int off = lds_off<D>(c / CH_PER_ROW, c % CH_PER_ROW);
+            *(u32x4 *)(smem + buf * TILE_BYTES + off) = kreg[i];
+            *(u32x4 *)(smem + (2 + buf) * TILE_BYTES + off) = vreg[i];
+        }
+    };
+
+    if (n_min < n_max) {
+        load_tile(n_min);
+        store_tile(0);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+
+    for (int n = n_min; n < n_max; ++n) {
+        const int cur = (n - n_min) & 1;
+        const bool has_next = n + 1 < n_max;
+        if (has_next) load_tile(n + 1);
+
+        const int k0 = n * BLOCK_N;
+        bool skip = !wave_active;
+        if (p.window_right >= 0) skip = skip || (k0 > wrow + 31 + shift + p.window_right);
+        if (p.window_left >= 0) skip = skip || (k0 + BLOCK_N - 1 < wrow + shift - p.window_left);
+
+        if (!skip) {
+            const char *kbuf = smem + cur * TILE_BYTES;
+            const char *vbuf = smem + (2 + cur) * TILE_BYTES;
+            // ---- S^T = K Q^T, dP^T = V dO^T: two 32-key blocks, query on the lane ------------------------
+            f32x16 s[2], dp[2];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { s[0][i] = 0.f; s[1][i] = 0.f; dp[0][i] = 0.f; dp[1][i] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+                const int off = lds_off<D>(r, 2 * ks + hh);
+                const u32x4 ka0 = *(const u32x4 *)(kbuf + off);
+                const u32x4 ka1 = *(const u32x4 *)(kbuf + off + 32 * D * 2);
+                const u32x4 va0 = *(const u32x4 *)(vbuf + off);
+                const u32x4 va1 = *(const u32x4 *)(vbuf + off + 32 * D * 2);
+                s[0] = Elem<T>::mma(ka0, qf[ks], s[0]);
+                s[1] = Elem<T>::mma(ka1, qf[ks], s[1]);
+                dp[0] = Elem<T>::mma(va0, gf[ks], dp[0]);
+                dp[1] = Elem<T>::mma(va1, gf[ks], dp[1]);
+            }
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int key = k0 + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                    const int rel = my_row + shift - key;
+                    bool vis = (key < sk) && (my_row < sq);
+                    if (p.window_right >= 0) vis = vis && (rel + p.window_right >= 0);
+                    if (p.window_left >= 0) vis = vis && (rel <= p.window_left);
+                    float pv, ds;
+                    bwd_point<SOFTCAP>(p, s[kb][i], dp[kb][i], lse2, dsum, alibi2, rel, vis, pv, ds);
+                    dp[kb][i] = ds;
+                }
+            u32x4 dsf[4];
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const int kb = st >> 1, b8 = (st & 1) * 8;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dsf[st][j] = Elem<T>::pack2(dp[kb][b8 + 2 * j], dp[kb][b8 + 2 * j + 1]);
+            }
+            // ---- dQ^T += K^T dS^T ------------------------------------------------------------------------
+#pragma unroll
+            for (int db = 0; db < DBLOCKS; ++db) {
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    u32x4 kt;
+#pragma unroll
+                    for (int j2 = 0; j2 < 2; ++j2) {
+                        const int row = 16 * st + 8 * j2 + 4 * hh + (i16 >> 2);
+                        const int ch = db * 4 + 2 * g1 + ((i16 >> 1) & 1);
+                        const int off = lds_off<D>(row, ch) + 8 * (i16 & 1);
+                        const u32x2 a = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) s16x4 *)(kbuf + off)));
+                        kt[2 * j2] = a[0];
+                        kt[2 * j2 + 1] = a[1];
+                    }
+                    dq_acc[db] = Elem<T>::mma(kt, dsf[st], dq_acc[db]);
+                }
+            }
+        }
+
+        if (has_next) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue ---------------------------------------------------------------------------------------------
+    T *dqp = (T *)p.dq + sq_.dq_base + (int64_t)head * p.dq_head_stride;
+    if (wave_active) {
+        char *obuf = smem + wave * (32 * O_ROW_BYTES);
+#pragma unroll
+        for (int db = 0; db < DBLOCKS; ++db)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                u32x2 w;
+                w[0] = Elem<T>::pack2(dq_acc[db][4 * g4] * p.out_scale, dq_acc[db][4 * g4 + 1] * p.out_scale);
+                w[1] = Elem<T>::pack2(dq_acc[db][4 * g4 + 2] * p.out_scale, dq_acc[db][4 * g4 + 3] * p.out_scale);
+                *(u32x2 *)(obuf + r * O_ROW_BYTES + (db * 32 + 8 * g4 + 4 * hh) * 2) = w;
+            }
+    }
+    __syncthreads();
+    if (wave_active) {
+        const char *obuf = smem + wave * (32 * O_ROW_BYTES);
+#pragma unroll
+        for (int i = 0; i < (32 * CH_PER_ROW) / 64; ++i) {
+            const int c = lane + i * 64;
+            const int row = c / CH_PER_ROW, ch = c % CH_PER_ROW;
+            if (wrow + row < sq && ch * 8 < p.d) {
+                const u32x4 val = *(const u32x4 *)(obuf + row * O_ROW_BYTES + ch * 16);
+                *(u32x4 *)(dqp + (int64_t)(wrow + row) * p.dq_row_stride + ch * 8) = val;
+            }
+        }
+    }
+}
+
+template <int D>
+constexpr int smem_bytes_dq() {
+    constexpr int kv = 4 * BLOCK_N * D * 2;
+    constexpr int o = 4 * 32 * (D * 2 + 16);
+    return kv > o ? kv : o;
+}
+
+}  // namespace fa

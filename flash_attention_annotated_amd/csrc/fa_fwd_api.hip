@@ -220,6 +220,9 @@ int fa_fwd_validate(const fa_fwd_params *p) {
             return FA_ERR_WORKSPACE;
     }
     if (p->softcap < 0.f || std::isnan(p->softcap) || std::isnan(p->softmax_scale)) return FA_ERR_BAD_SHAPE;
+    if (p->alibi_slopes && (reinterpret_cast<uintptr_t>(p->alibi_slopes) % 4 != 0 || p->alibi_slopes_batch_stride < 0 ||
+                            p->alibi_slopes_batch_stride > 0x7fffffff))
+        return FA_ERR_BAD_STRIDE;
     return FA_OK;
 }
 
@@ -299,6 +302,9 @@ int fa_fwd(const fa_fwd_params *p, void *stream_) {
     if (wl >= 0 && wr < 0) wr = p->seqlen_k;
     kp.window_left = wl;
     kp.window_right = wr;
+
+    kp.alibi = p->alibi_slopes;
+    kp.alibi_bs = (int32_t)p->alibi_slopes_batch_stride;
 
     const bool softcap = p->softcap > 0.f;
     constexpr float kLog2e = 1.4426950408889634f;

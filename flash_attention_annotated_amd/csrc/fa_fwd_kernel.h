@@ -62,12 +62,20 @@ struct KParams {
     // v into the final O normalisation (hopper/flash_fwd_kernel_sm90.h:408-415, mainloop_fwd_sm90...hpp:1241-1250).
     const float *q_descale, *k_descale, *v_descale;
     int32_t qd_bs, qd_hs, kd_bs, kd_hs, vd_bs, vd_hs;  // element strides (batch, head)
+    const float *alibi;    // ALiBi slopes (h) or (b, h), NULL = off
+    int32_t alibi_bs;      // batch stride of alibi (0 for the (h) form)
 };
 
 // per-workgroup effective scales for (batch, kv_head)
 struct Scales {
     float scale, scale_log2, softcap_pre, v_descale;
 };
+// ALiBi slope of (batch, head) in units of the raw score the kernels carry (bias = -slope * |i + sk - sq - j| is
+// defined on the scaled score: divide by the factor the softmax multiplies scores with).  0 = off.
+__device__ __forceinline__ float load_alibi(const KParams &p, const Scales &sc, int batch, int head) {
+    if (!p.alibi) return 0.f;
+    return p.alibi[(int64_t)batch * p.alibi_bs + head] / sc.scale;
+}
 __device__ __forceinline__ Scales load_scales(const KParams &p, int batch, int kv_head) {
     float qk = 1.f, vd = 1.f;
     if (p.q_descale) qk *= p.q_descale[batch * p.qd_bs + kv_head * p.qd_hs];
@@ -226,6 +234,7 @@ __global__ __launch_bounds__(NWAVES * 64, (D <= 128 ? 2 : 1)) void fwd_kernel(co
     const int row_lo = m_block * BLOCK_M;
     if (row_lo >= sq) return;  // whole workgroup: nothing to do (varlen / padded grid)
     const Scales sc = load_scales(p, batch, kv_head);
+    const float alibi = load_alibi(p, sc, batch, head);
 
     const T *qp = (const T *)p.q + q_base + (int64_t)head * p.q_head_stride;
     const T *kp = (const T *)p.k + k_base + (int64_t)kv_head * p.k_head_stride;
@@ -357,6 +366,17 @@ __global__ __launch_bounds__(NWAVES * 64, (D <= 128 ? 2 : 1)) void fwd_kernel(co
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                     for (int i = 0; i < 16; ++i) s[kb][i] = fast_tanh(s[kb][i] * sc.softcap_pre);
+            }
+
+            if (p.alibi) {  // wave-uniform; bias on the (soft-capped) score, before masking: src/mask.h:156-186
+                const int rel0 = my_row + shift - k0 - 4 * hh;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int rel = rel0 - (kb * 32 + (i & 3) + 8 * (i >> 2));
+                        s[kb][i] -= alibi * fabsf((float)rel);
+                    }
             }
 
             // ---- mask (boundary tiles only) -----------------------------------------------------

@@ -390,6 +390,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     // struct as s_load_dwordx8/x16 tuples and, once those spill, reloads a whole tuple through v_readlane -- VALU
     // instructions -- every tile just to reach one field).  The empty asm makes each one a fresh scalar value.
     const Scales sc = load_scales(p, batch, kv_head);
+    const float alibi = load_alibi(p, sc, batch, head);
     int64_t k_rs64 = p.k_row_stride, v_rs64 = p.v_row_stride;
     // (scale * descale is a VALU product: bring it back to an SGPR by value, not by int conversion)
     float csc_arg = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sc.scale_log2)));
@@ -548,6 +549,16 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
             for (int i = 0; i < 16; ++i) {
                 sa[i] = fast_tanh(sa[i] * sc.softcap_pre);
                 sb[i] = fast_tanh(sb[i] * sc.softcap_pre);
+            }
+        }
+        if (p.alibi) {  // wave-uniform; bias on the (soft-capped) score, before masking: src/mask.h:156-186
+            const int k0 = n_min * BLOCK_N + 32 * j + 4 * hh;
+            const int rel_a = row_a + shift - k0, rel_b = row_b + shift - k0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int key = (i & 3) + 8 * (i >> 2);
+                sa[i] -= alibi * fabsf((float)(rel_a - key));
+                sb[i] -= alibi * fabsf((float)(rel_b - key));
             }
         }
         if (half_needs_mask(j)) {
@@ -828,7 +839,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     // jj of a fast tile pair [j, j+4) needs jj + 1 <= fast_last
     int fast_last = -1;
     const int seq_last = __builtin_amdgcn_readfirstlane((sk - n_min * BLOCK_N) / 32 - 1);  // last half-step wholly < sk
-    if (!SOFTCAP && p.window_left < 0 && jend > 0) {
+    if (!SOFTCAP && p.window_left < 0 && jend > 0 && !p.alibi) {
         int nomask = (sk - n_min * BLOCK_N) / 32 - 1;
         if (p.window_right >= 0) {
             const int t = wrow + shift + p.window_right - 31 - n_min * BLOCK_N;

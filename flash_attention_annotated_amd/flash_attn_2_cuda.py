@@ -9,7 +9,8 @@ checks, output allocation, params — and enqueue the gfx950 kernel through the 
 (`include/fa_fwd.h`) on torch's current stream.  Error texts are the reference's
 `TORCH_CHECK` messages, raised as RuntimeError like c10::Error is.
 
-Only the forward hot path is built: `bwd`, `varlen_bwd`, `fwd_kvcache` raise.
+`bwd` / `varlen_bwd` do the same for mha_bwd (:767-971) / mha_varlen_bwd (:973-1200) through include/fa_bwd.h.
+`fwd_kvcache` (decode path) is not built and raises.
 """
 import math
 from typing import List, Optional
@@ -43,12 +44,23 @@ def _check_shape(x, name, *shape):
     _check(tuple(x.shape) == tuple(shape), f"{name} must have shape ({', '.join(str(s) for s in shape)})")
 
 
-def _reject_unbuilt(alibi_slopes_, p_dropout, return_softmax):
+def _reject_unbuilt(p_dropout, return_softmax):
     # accepted positionally like the reference; rejected by message like the reference does for
     # compiled-out features (hopper/flash_api.cpp:1148-1165)
-    _check(alibi_slopes_ is None, "This flash attention build does not support alibi.")
     _check(p_dropout == 0.0, "This flash attention build does not support dropout.")
     _check(not return_softmax, "return_softmax is only supported when p_dropout > 0.0")
+
+
+def _check_alibi(alibi_slopes_, batch_size, num_heads):
+    """set_params_alibi, csrc/flash_attn/flash_api.cpp:331-349."""
+    if alibi_slopes_ is None:
+        return None
+    _check(alibi_slopes_.dtype == torch.float32, "ALiBi slopes must have dtype fp32")
+    _check_device(alibi_slopes_, "alibi_slopes")
+    _check(alibi_slopes_.stride(-1) == 1, "ALiBi slopes tensor must have contiguous last dimension")
+    _check(tuple(alibi_slopes_.shape) in ((num_heads,), (batch_size, num_heads)),
+           "alibi_slopes must have shape (num_heads) or (batch_size, num_heads)")
+    return alibi_slopes_
 
 
 def fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out_: Optional[torch.Tensor],
@@ -74,7 +86,8 @@ def fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out_: Optional[torch.
     _check(num_heads % num_heads_k == 0, "Number of heads in key/value must divide number of heads in query")
     if softcap > 0.0:
         _check(p_dropout == 0.0, "Softcapping does not support dropout for now")
-    _reject_unbuilt(alibi_slopes_, p_dropout, return_softmax)
+    _reject_unbuilt(p_dropout, return_softmax)
+    alibi = _check_alibi(alibi_slopes_, batch_size, num_heads)
 
     # causal=true is the same as causal=false in this case (:402)
     if seqlen_q == 1 and alibi_slopes_ is None:
@@ -103,7 +116,8 @@ def fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out_: Optional[torch.
             oc = out if _aligned(out) else torch.empty_like(qc)
             _dispatch.launch(qc, kc, vc, oc, softmax_lse, varlen=False, batch=batch_size, max_seqlen_q=seqlen_q,
                              max_seqlen_k=seqlen_k, softmax_scale=softmax_scale, causal=is_causal,
-                             window_left=window_size_left, window_right=window_size_right, softcap=softcap)
+                             window_left=window_size_left, window_right=window_size_right, softcap=softcap,
+                             alibi_slopes=alibi)
             if oc is not out:
                 out.copy_(oc)
         elif seqlen_q > 0:
@@ -147,7 +161,8 @@ def varlen_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out_: Optional
     _check(num_heads % num_heads_k == 0, "Number of heads in key/value must divide number of heads in query")
     if softcap > 0.0:
         _check(p_dropout == 0.0, "Softcapping does not support dropout for now")
-    _reject_unbuilt(alibi_slopes_, p_dropout, return_softmax)
+    _reject_unbuilt(p_dropout, return_softmax)
+    alibi = _check_alibi(alibi_slopes_, batch_size, num_heads)
 
     if max_seqlen_q == 1 and alibi_slopes_ is None:
         is_causal = False  # (:590)
@@ -186,7 +201,8 @@ def varlen_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out_: Optional
             _dispatch.launch(qc, kc, vc, oc, softmax_lse, varlen=True, batch=batch_size, max_seqlen_q=max_seqlen_q,
                              max_seqlen_k=max_seqlen_k, softmax_scale=softmax_scale, causal=is_causal,
                              window_left=window_size_left, window_right=window_size_right, softcap=softcap,
-                             cu_seqlens_q=cu_seqlens_q, cu_seqlens_k=cu_seqlens_k, seqused_k=seqused_k)
+                             cu_seqlens_q=cu_seqlens_q, cu_seqlens_k=cu_seqlens_k, seqused_k=seqused_k,
+                             alibi_slopes=alibi)
             if oc is not out:
                 out.copy_(oc)
         elif total_q > 0:
@@ -195,14 +211,149 @@ def varlen_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out_: Optional
     return [out, softmax_lse, p, rng_state]
 
 
-def bwd(*args, **kwargs):
-    """mha_bwd, csrc/flash_attn/flash_api.cpp:767 — outside the forward hot path."""
-    raise RuntimeError("flash_attn_2_cuda.bwd: the backward pass is not built in this forward-only back-end")
+def _grad_out(given, like, name, shape):
+    if given is None:
+        return torch.empty_like(like)
+    _check(given.dtype == like.dtype, f"{name} must have the same dtype as q")
+    _check_device(given, name)
+    _check(given.stride(-1) == 1, f"{name} must have contiguous last dimension")
+    _check_shape(given, name, *shape)
+    return given
 
 
-def varlen_bwd(*args, **kwargs):
-    """mha_varlen_bwd, csrc/flash_attn/flash_api.cpp:973 — not built."""
-    raise RuntimeError("flash_attn_2_cuda.varlen_bwd: the backward pass is not built in this forward-only back-end")
+def _round_multiple(x, m):
+    return (x + m - 1) // m * m
+
+
+def bwd(dout: torch.Tensor, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor,
+        softmax_lse: torch.Tensor, dq_: Optional[torch.Tensor], dk_: Optional[torch.Tensor],
+        dv_: Optional[torch.Tensor], alibi_slopes_: Optional[torch.Tensor], p_dropout: float, softmax_scale: float,
+        is_causal: bool, window_size_left: int, window_size_right: int, softcap: float, deterministic: bool,
+        gen_: Optional[torch.Generator], rng_state: Optional[torch.Tensor]) -> List[torch.Tensor]:
+    """mha_bwd, csrc/flash_attn/flash_api.cpp:767-971.  Returns [dq, dk, dv, softmax_d]."""
+    _lib.load()
+    q_dtype = q.dtype
+    _check(q_dtype in (torch.float16, torch.bfloat16), "FlashAttention only support fp16 and bf16 data type")
+    _check(k.dtype == q_dtype, "query and key must have the same dtype")
+    _check(v.dtype == q_dtype, "query and value must have the same dtype")
+    _check(out.dtype == q_dtype, "query and out must have the same dtype")
+    _check(dout.dtype == q_dtype, "query and dout must have the same dtype")
+    for t, n in ((q, "q"), (k, "k"), (v, "v"), (out, "out"), (dout, "dout"), (softmax_lse, "softmax_lse")):
+        _check_device(t, n)
+    for t in (q, k, v):
+        _check(t.stride(-1) == 1, "Input tensor must have contiguous last dimension")
+    _check(out.stride(-1) == 1, "out tensor must have contiguous last dimension")
+    _check(dout.stride(-1) == 1, "dout tensor must have contiguous last dimension")
+
+    batch_size, seqlen_q, num_heads, head_size = q.shape
+    seqlen_k, num_heads_k = k.shape[1], k.shape[2]
+    _check(batch_size > 0, "batch size must be positive")
+    _check(head_size % 8 == 0, "head_size should be a multiple of 8")
+    _check(head_size <= 256, "FlashAttention backward only supports head dimension at most 256")
+    _check(num_heads % num_heads_k == 0, "Number of heads in key/value must divide number of heads in query")
+    if softcap > 0.0:
+        _check(p_dropout == 0.0, "Softcapping does not support dropout for now")
+    _check(p_dropout == 0.0, "This flash attention build does not support dropout.")
+    alibi = _check_alibi(alibi_slopes_, batch_size, num_heads)
+
+    _check_shape(q, "q", batch_size, seqlen_q, num_heads, head_size)
+    _check_shape(k, "k", batch_size, seqlen_k, num_heads_k, head_size)
+    _check_shape(v, "v", batch_size, seqlen_k, num_heads_k, head_size)
+    _check_shape(out, "out", batch_size, seqlen_q, num_heads, head_size)
+    _check_shape(dout, "dout", batch_size, seqlen_q, num_heads, head_size)
+    dq = _grad_out(dq_, q, "dq", (batch_size, seqlen_q, num_heads, head_size))
+    dk = _grad_out(dk_, k, "dk", (batch_size, seqlen_k, num_heads_k, head_size))
+    dv = _grad_out(dv_, v, "dv", (batch_size, seqlen_k, num_heads_k, head_size))
+
+    with torch.cuda.device(q.device):
+        softmax_d = torch.empty((batch_size, num_heads, _round_multiple(seqlen_q, 128)), dtype=torch.float32,
+                                device=q.device)
+        if seqlen_q > 0 and seqlen_k > 0:
+            ins = [x if _aligned(x) else x.contiguous() for x in (dout, q, k, v, out)]
+            outs = [x if _aligned(x) else torch.empty_like(x, memory_format=torch.contiguous_format) for x in (dq, dk, dv)]
+            lse = softmax_lse if softmax_lse.is_contiguous() else softmax_lse.contiguous()
+            _dispatch.launch_bwd(*ins, lse, *outs, softmax_d, varlen=False, batch=batch_size, max_seqlen_q=seqlen_q,
+                                 max_seqlen_k=seqlen_k, softmax_scale=softmax_scale, causal=is_causal,
+                                 window_left=window_size_left, window_right=window_size_right, softcap=softcap,
+                                 alibi_slopes=alibi, deterministic=deterministic)
+            for dst, src in zip((dq, dk, dv), outs):
+                if dst is not src:
+                    dst.copy_(src)
+        else:
+            # If seqlen_q == 0 (or there are no keys), the gradients are zero (:953-958)
+            dq.zero_(); dk.zero_(); dv.zero_(); softmax_d.zero_()
+    return [dq, dk, dv, softmax_d]
+
+
+def varlen_bwd(dout: torch.Tensor, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor,
+               softmax_lse: torch.Tensor, dq_: Optional[torch.Tensor], dk_: Optional[torch.Tensor],
+               dv_: Optional[torch.Tensor], cu_seqlens_q: torch.Tensor, cu_seqlens_k: torch.Tensor,
+               alibi_slopes_: Optional[torch.Tensor], max_seqlen_q: int, max_seqlen_k: int, p_dropout: float,
+               softmax_scale: float, zero_tensors: bool, is_causal: bool, window_size_left: int,
+               window_size_right: int, softcap: float, deterministic: bool, gen_: Optional[torch.Generator],
+               rng_state: Optional[torch.Tensor]) -> List[torch.Tensor]:
+    """mha_varlen_bwd, csrc/flash_attn/flash_api.cpp:973-1200.  Returns [dq, dk, dv, softmax_d]."""
+    _lib.load()
+    q_dtype = q.dtype
+    _check(q_dtype in (torch.float16, torch.bfloat16), "FlashAttention only support fp16 and bf16 data type")
+    _check(k.dtype == q_dtype, "query and key must have the same dtype")
+    _check(v.dtype == q_dtype, "query and value must have the same dtype")
+    _check(out.dtype == q_dtype, "query and out must have the same dtype")
+    _check(dout.dtype == q_dtype, "query and dout must have the same dtype")
+    _check(cu_seqlens_q.dtype == torch.int32, "cu_seqlens_q must have dtype int32")
+    _check(cu_seqlens_k.dtype == torch.int32, "cu_seqlens_k must have dtype int32")
+    for t, n in ((q, "q"), (k, "k"), (v, "v"), (out, "out"), (dout, "dout"), (softmax_lse, "softmax_lse"),
+                 (cu_seqlens_q, "cu_seqlens_q"), (cu_seqlens_k, "cu_seqlens_k")):
+        _check_device(t, n)
+    for t in (q, k, v):
+        _check(t.stride(-1) == 1, "Input tensor must have contiguous last dimension")
+    _check(out.stride(-1) == 1, "out tensor must have contiguous last dimension")
+    _check(dout.stride(-1) == 1, "dout tensor must have contiguous last dimension")
+    _check(cu_seqlens_q.is_contiguous(), "cu_seqlens_q must be contiguous")
+    _check(cu_seqlens_k.is_contiguous(), "cu_seqlens_k must be contiguous")
+
+    total_q, num_heads, head_size = q.shape
+    batch_size = cu_seqlens_q.numel() - 1
+    total_k, num_heads_k = k.shape[0], k.shape[1]
+    _check(batch_size > 0, "batch size must be positive")
+    _check(head_size % 8 == 0, "head_size should be a multiple of 8")
+    _check(head_size <= 256, "FlashAttention backward only supports head dimension at most 256")
+    _check(num_heads % num_heads_k == 0, "Number of heads in key/value must divide number of heads in query")
+    if softcap > 0.0:
+        _check(p_dropout == 0.0, "Softcapping does not support dropout for now")
+    _check(p_dropout == 0.0, "This flash attention build does not support dropout.")
+    alibi = _check_alibi(alibi_slopes_, batch_size, num_heads)
+
+    _check_shape(q, "q", total_q, num_heads, head_size)
+    _check_shape(k, "k", total_k, num_heads_k, head_size)
+    _check_shape(v, "v", total_k, num_heads_k, head_size)
+    _check_shape(out, "out", total_q, num_heads, head_size)
+    _check_shape(dout, "dout", total_q, num_heads, head_size)
+    _check_shape(cu_seqlens_q, "cu_seqlens_q", batch_size + 1)
+    _check_shape(cu_seqlens_k, "cu_seqlens_k", batch_size + 1)
+    dq = _grad_out(dq_, q, "dq", (total_q, num_heads, head_size))
+    dk = _grad_out(dk_, k, "dk", (total_k, num_heads_k, head_size))
+    dv = _grad_out(dv_, v, "dv", (total_k, num_heads_k, head_size))
+
+    with torch.cuda.device(q.device):
+        softmax_d = torch.empty((num_heads, total_q + 128 * batch_size), dtype=torch.float32, device=q.device)
+        if zero_tensors:
+            dq.zero_(); dk.zero_(); dv.zero_(); softmax_d.zero_()
+        if max_seqlen_q > 0 and total_q > 0 and total_k > 0:
+            ins = [x if _aligned(x) else x.contiguous() for x in (dout, q, k, v, out)]
+            outs = [x if _aligned(x) else torch.empty_like(x, memory_format=torch.contiguous_format) for x in (dq, dk, dv)]
+            lse = softmax_lse if softmax_lse.is_contiguous() else softmax_lse.contiguous()
+            _dispatch.launch_bwd(*ins, lse, *outs, softmax_d, varlen=True, batch=batch_size,
+                                 max_seqlen_q=max_seqlen_q, max_seqlen_k=max_seqlen_k, softmax_scale=softmax_scale,
+                                 causal=is_causal, window_left=window_size_left, window_right=window_size_right,
+                                 softcap=softcap, cu_seqlens_q=cu_seqlens_q, cu_seqlens_k=cu_seqlens_k,
+                                 alibi_slopes=alibi, deterministic=deterministic)
+            for dst, src in zip((dq, dk, dv), outs):
+                if dst is not src:
+                    dst.copy_(src)
+        else:
+            dq.zero_(); dk.zero_(); dv.zero_(); softmax_d.zero_()
+    return [dq, dk, dv, softmax_d]
 
 
 def fwd_kvcache(*args, **kwargs):

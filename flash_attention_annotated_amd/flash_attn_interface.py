@@ -1,4 +1,4 @@
-"""Public Python API of the forward hot path — same names, arguments, defaults and return
+"""Public Python API of the attention op (forward hot path + its backward) — same names, arguments, defaults and return
 conventions as the reference's `flash_attn/flash_attn_interface.py`:
 
     flash_attn_func                     reference :1145-1219
@@ -44,6 +44,30 @@ def _flash_attn_forward(q, k, v, dropout_p, softmax_scale, causal, window_size_l
     return out, softmax_lse, S_dmask, rng_state
 
 
+def _flash_attn_backward(dout, q, k, v, out, softmax_lse, dq, dk, dv, dropout_p, softmax_scale, causal,
+                         window_size_left, window_size_right, softcap, alibi_slopes, deterministic,
+                         rng_state=None) -> torch.Tensor:
+    """reference :241-289"""
+    dout, q, k, v, out = [maybe_contiguous(x) for x in (dout, q, k, v, out)]
+    dq, dk, dv, softmax_d = flash_attn_gpu.bwd(
+        dout, q, k, v, out, softmax_lse, dq, dk, dv, alibi_slopes, dropout_p, softmax_scale, causal,
+        window_size_left, window_size_right, softcap, deterministic, None, rng_state)
+    return softmax_d
+
+
+def _flash_attn_varlen_backward(dout, q, k, v, out, softmax_lse, dq, dk, dv, cu_seqlens_q, cu_seqlens_k,
+                                max_seqlen_q, max_seqlen_k, dropout_p, softmax_scale, causal, window_size_left,
+                                window_size_right, softcap, alibi_slopes, deterministic, rng_state=None,
+                                zero_tensors=False) -> torch.Tensor:
+    """reference :337-392"""
+    dout, q, k, v, out = [maybe_contiguous(x) for x in (dout, q, k, v, out)]
+    dq, dk, dv, softmax_d = flash_attn_gpu.varlen_bwd(
+        dout, q, k, v, out, softmax_lse, dq, dk, dv, cu_seqlens_q, cu_seqlens_k, alibi_slopes, max_seqlen_q,
+        max_seqlen_k, dropout_p, softmax_scale, zero_tensors, causal, window_size_left, window_size_right, softcap,
+        deterministic, None, rng_state)
+    return softmax_d
+
+
 def _flash_attn_varlen_forward(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, dropout_p,
                                softmax_scale, causal, window_size_left=-1, window_size_right=-1, softcap=0.0,
                                alibi_slopes=None, return_softmax=False, block_table=None, leftpad_k=None,
@@ -62,6 +86,7 @@ class FlashAttnFunc(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, dropout_p, softmax_scale, causal, window_size, softcap, alibi_slopes,
                 deterministic, return_softmax, is_grad_enabled):
+        is_grad = is_grad_enabled and any(x.requires_grad for x in [q, k, v])
         if softmax_scale is None:
             softmax_scale = q.shape[-1] ** (-0.5)
         head_size_og = q.size(-1)
@@ -70,12 +95,29 @@ class FlashAttnFunc(torch.autograd.Function):
             qp, kp, vp, dropout_p, softmax_scale, causal=causal, window_size_left=window_size[0],
             window_size_right=window_size[1], softcap=softcap, alibi_slopes=alibi_slopes,
             return_softmax=return_softmax and dropout_p > 0)
+        if is_grad:
+            ctx.save_for_backward(qp, kp, vp, out_padded, softmax_lse, rng_state)
+            ctx.dropout_p = dropout_p
+            ctx.softmax_scale = softmax_scale
+            ctx.causal = causal
+            ctx.window_size = window_size
+            ctx.softcap = softcap
+            ctx.alibi_slopes = alibi_slopes
+            ctx.deterministic = deterministic
         out = out_padded[..., :head_size_og]
         return out if not return_softmax else (out, softmax_lse, S_dmask)
 
     @staticmethod
     def backward(ctx, dout, *args):
-        flash_attn_gpu.bwd()  # raises: forward-only back-end
+        """reference :869-900"""
+        q, k, v, out, softmax_lse, rng_state = ctx.saved_tensors
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        (dout_padded,) = _pad_head_dim(dout)
+        _flash_attn_backward(dout_padded, q, k, v, out, softmax_lse, dq, dk, dv, ctx.dropout_p, ctx.softmax_scale,
+                             ctx.causal, ctx.window_size[0], ctx.window_size[1], ctx.softcap, ctx.alibi_slopes,
+                             ctx.deterministic, rng_state=rng_state)
+        d = dout.shape[-1]  # the head dimension may have been padded
+        return dq[..., :d], dk[..., :d], dv[..., :d], None, None, None, None, None, None, None, None, None
 
 
 class FlashAttnVarlenFunc(torch.autograd.Function):
@@ -83,6 +125,7 @@ class FlashAttnVarlenFunc(torch.autograd.Function):
     def forward(ctx, q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, dropout_p, softmax_scale,
                 causal, window_size, softcap, alibi_slopes, deterministic, return_softmax, block_table,
                 is_grad_enabled):
+        is_grad = is_grad_enabled and any(x.requires_grad for x in [q, k, v])
         if softmax_scale is None:
             softmax_scale = q.shape[-1] ** (-0.5)
         head_size_og = q.size(-1)
@@ -91,12 +134,33 @@ class FlashAttnVarlenFunc(torch.autograd.Function):
             qp, kp, vp, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, dropout_p, softmax_scale,
             causal=causal, window_size_left=window_size[0], window_size_right=window_size[1], softcap=softcap,
             alibi_slopes=alibi_slopes, return_softmax=return_softmax and dropout_p > 0, block_table=block_table)
+        if is_grad:
+            ctx.save_for_backward(qp, kp, vp, out_padded, softmax_lse, cu_seqlens_q, cu_seqlens_k, rng_state)
+            ctx.dropout_p = dropout_p
+            ctx.max_seqlen_q = max_seqlen_q
+            ctx.max_seqlen_k = max_seqlen_k
+            ctx.softmax_scale = softmax_scale
+            ctx.causal = causal
+            ctx.window_size = window_size
+            ctx.softcap = softcap
+            ctx.alibi_slopes = alibi_slopes
+            ctx.deterministic = deterministic
         out = out_padded[..., :head_size_og]
         return out if not return_softmax else (out, softmax_lse, S_dmask)
 
     @staticmethod
     def backward(ctx, dout, *args):
-        flash_attn_gpu.varlen_bwd()  # raises: forward-only back-end
+        """reference :970-1005"""
+        q, k, v, out, softmax_lse, cu_seqlens_q, cu_seqlens_k, rng_state = ctx.saved_tensors
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        (dout_padded,) = _pad_head_dim(dout)
+        _flash_attn_varlen_backward(dout_padded, q, k, v, out, softmax_lse, dq, dk, dv, cu_seqlens_q, cu_seqlens_k,
+                                    ctx.max_seqlen_q, ctx.max_seqlen_k, ctx.dropout_p, ctx.softmax_scale, ctx.causal,
+                                    ctx.window_size[0], ctx.window_size[1], ctx.softcap, ctx.alibi_slopes,
+                                    ctx.deterministic, rng_state=rng_state)
+        d = dout.shape[-1]
+        return (dq[..., :d], dk[..., :d], dv[..., :d], None, None, None, None, None, None, None, None, None, None,
+                None, None, None, None)
 
 
 def flash_attn_func(q, k, v, dropout_p=0.0, softmax_scale=None, causal=False, window_size=(-1, -1),

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define FA_ABI_VERSION 2
+#define FA_ABI_VERSION 3
 
 /* element types of q/k/v (o has the same type; fp8 inputs produce bf16 o) */
 enum fa_dtype {
@@ -55,7 +55,7 @@ enum fa_status {
     FA_ERR_BAD_HEADS = -4,         /* h % h_k != 0 */
     FA_ERR_BAD_SHAPE = -5,         /* b <= 0, negative lengths, ... */
     FA_ERR_BAD_STRIDE = -6,        /* misaligned rows: strides must keep 16-byte row alignment */
-    FA_ERR_UNSUPPORTED = -7,       /* feature accepted by the ABI but not built (alibi, dropout, ...) */
+    FA_ERR_UNSUPPORTED = -7,       /* feature accepted by the ABI but not built (dropout, ...) */
     FA_ERR_LAUNCH = -8,            /* hipLaunchKernel failed */
     FA_ERR_BAD_ABI = -9,           /* params->abi_version / struct size mismatch */
     FA_ERR_NO_DEVICE = -10,        /* not a gfx950 device */
@@ -124,6 +124,13 @@ typedef struct fa_fwd_params {
      * the descales folded into the softmax scale and the final normalisation. */
     void *workspace;
     uint64_t workspace_bytes;
+
+    /* ALiBi (csrc/flash_attn/src/alibi.h:18-71, set_params_alibi csrc/flash_attn/flash_api.cpp:331-349): fp32 slopes,
+     * (h) [batch stride 0] or (b, h); NULL = off.  The bias added to the scaled (and soft-capped) score of query i,
+     * key j is  -slope * |i + seqlen_k - seqlen_q - j|  (tests/test_flash_attn.py:29-56); under a causal mask this
+     * differs from the reference kernel's  +slope * j  only by a per-row constant (same O; LSE includes the bias). */
+    const float *alibi_slopes;
+    int64_t alibi_slopes_batch_stride;
 } fa_fwd_params;
 
 /* Validate and enqueue the forward on `stream` (a hipStream_t; NULL = default

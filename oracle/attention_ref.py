@@ -34,6 +34,23 @@ def local_mask(seqlen_q, seqlen_k, window_size=(-1, -1), query_padding_mask=None
     return torch.logical_or(j > torch.minimum(diag + right, sk_t), j < diag - left)
 
 
+def attn_bias_from_alibi_slopes(slopes, seqlen_q, seqlen_k, query_padding_mask=None, key_padding_mask=None,
+                                causal=False):
+    """ALiBi bias (b, h, sq|1, sk) from fp32 slopes (b, h): tests/test_flash_attn.py:29-56.
+    non-causal: -slope * |i + sk - sq - j| (sk, sq = per-batch valid lengths under padding masks);
+    causal: slope * (j - seqlen_k + 1), the same for every row (equal to the general form up to a per-row constant,
+    which softmax cancels)."""
+    b, h = slopes.shape
+    sl = slopes.view(b, h, 1, 1)
+    if causal:
+        return torch.arange(-seqlen_k + 1, 1, dtype=torch.float32, device=slopes.device) * sl
+    i = torch.arange(seqlen_q, dtype=torch.long, device=slopes.device).view(-1, 1)
+    j = torch.arange(seqlen_k, dtype=torch.long, device=slopes.device)
+    sk = seqlen_k if key_padding_mask is None else key_padding_mask.sum(-1).view(-1, 1, 1, 1)
+    sq = seqlen_q if query_padding_mask is None else query_padding_mask.sum(-1).view(-1, 1, 1, 1)
+    return -sl * torch.abs(i + sk - sq - j).to(slopes.dtype)
+
+
 def attention_ref(q, k, v, query_padding_mask=None, key_padding_mask=None, attn_bias=None, causal=False,
                   window_size=(-1, -1), softcap=0.0, upcast=True, reorder_ops=False, return_lse=False,
                   q_descale=None, k_descale=None, v_descale=None, intermediate_dtype=None):

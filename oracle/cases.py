@@ -12,12 +12,12 @@ _DT = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}
 
 
 def _case(dtype, b, sq, sk, h, hk, d, causal=False, window=(-1, -1), softcap=0.0, padding="none", seed=0,
-          q_scale=1.0, store_row_stride=1, fp8=False):
-    if store_row_stride == 1:  # keep fixtures small: store every n-th query row of the big cases
+          q_scale=1.0, store_row_stride=0, fp8=False, alibi=False):
+    if store_row_stride == 0:  # keep fixtures small: store every n-th query row of the big cases
         store_row_stride = max(1, (b * sq * h * d) // 12288)
     return dict(dtype=dtype, b=b, sq=sq, sk=sk, h=h, hk=hk, d=d, causal=causal, window=tuple(window),
                 softcap=softcap, padding=padding, seed=seed, q_scale=q_scale, store_row_stride=store_row_stride,
-                fp8=fp8)
+                fp8=fp8, alibi=alibi)
 
 
 CASES = {
@@ -46,11 +46,36 @@ CASES = {
     # ragged batches (key / query padding)
     "bf16_padded_causal": _case("bf16", 3, 128, 217, 4, 2, 64, causal=True, padding="random", seed=16),
     "fp16_padded": _case("fp16", 3, 97, 97, 2, 2, 128, padding="random", seed=17),
+    # ALiBi: slopes rand(b, h) * 0.3 as tests/test_flash_attn.py:937
+    "bf16_alibi_113_203_gqa": _case("bf16", 2, 113, 203, 4, 2, 64, seed=20, alibi=True),
+    "bf16_alibi_causal_d128": _case("bf16", 2, 150, 150, 2, 2, 128, causal=True, seed=21, alibi=True),
+    "fp16_alibi_padded_local": _case("fp16", 2, 128, 160, 4, 4, 64, window=(40, 8), padding="random", seed=22,
+                                     alibi=True),
     # fp8 e4m3 storage (BASELINE config 5 in miniature): bf16 values rounded through e4m3 + per-(batch, kv head)
     # descales rand*2, exactly how hopper/test_flash_attn.py:135-147 builds its fp8 inputs
     "fp8_descale_gqa_d128": _case("bf16", 2, 160, 200, 4, 2, 128, seed=18, fp8=True),
     "fp8_descale_causal_d64": _case("bf16", 2, 130, 130, 4, 4, 64, causal=True, seed=19, fp8=True),
 }
+
+
+# Backward fixtures: small problems whose dq/dk/dv (reference oracle + autograd, the way tests/test_flash_attn.py:1071-1105
+# obtains dq_ref / dq_pt) are frozen in tests/golden/attention_grad_golden.pt.  Stored in full (store_row_stride = 1).
+GRAD_CASES = {
+    "grad_bf16_gqa_d32": _case("bf16", 2, 64, 96, 4, 2, 32, seed=40, store_row_stride=1),
+    "grad_fp16_causal_sq_ne_sk_d64": _case("fp16", 1, 100, 130, 2, 2, 64, causal=True, seed=41, store_row_stride=1),
+    "grad_bf16_causal_sq_gt_sk": _case("bf16", 1, 96, 40, 2, 1, 64, causal=True, seed=42, store_row_stride=1),
+    "grad_bf16_local_softcap": _case("bf16", 1, 128, 128, 2, 2, 64, window=(30, 10), softcap=20.0, q_scale=4.0,
+                                     seed=43, store_row_stride=1),
+    "grad_bf16_alibi_mqa": _case("bf16", 2, 80, 112, 2, 1, 64, seed=44, alibi=True, store_row_stride=1),
+    "grad_fp16_padded_causal_d128": _case("fp16", 2, 70, 90, 2, 2, 128, causal=True, padding="random", seed=45,
+                                          store_row_stride=1),
+}
+
+
+def make_grad_output(c):
+    """dO ~ N(0,1) in the case's dtype, (b, sq, h, d)."""
+    g = torch.Generator().manual_seed(5000 + c["seed"])
+    return torch.randn(c["b"], c["sq"], c["h"], c["d"], generator=g, dtype=torch.float32).to(_DT[c["dtype"]])
 
 
 def make_inputs(c):
@@ -73,6 +98,14 @@ def make_descales(c):
         return None, None, None
     g = torch.Generator().manual_seed(3000 + c["seed"])
     return tuple(torch.rand(c["b"], c["hk"], generator=g, dtype=torch.float32) * 2 for _ in range(3))
+
+
+def make_alibi_slopes(c):
+    """(b, h) fp32 slopes = rand * 0.3, or None."""
+    if not c.get("alibi"):
+        return None
+    g = torch.Generator().manual_seed(4000 + c["seed"])
+    return torch.rand(c["b"], c["h"], generator=g, dtype=torch.float32) * 0.3
 
 
 def padding_masks(c):

@@ -23,7 +23,7 @@ REF = "/root/reference"
 sys.path.insert(0, ROOT)
 
 from oracle import attention_ref as mine  # noqa: E402
-from oracle.cases import CASES, make_descales, make_inputs, padding_masks, checksum  # noqa: E402
+from oracle.cases import CASES, GRAD_CASES, make_grad_output, make_alibi_slopes, make_descales, make_inputs, padding_masks, checksum  # noqa: E402
 
 
 def import_reference():
@@ -39,6 +39,19 @@ def import_reference():
     fa3 = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fa3)
     return fa2, fa3
+
+
+def import_reference_alibi():
+    """attn_bias_from_alibi_slopes lives in tests/test_flash_attn.py (:29-56), a module that queries the GPU at import.
+    Only that one function is compiled out of the file's syntax tree and run here."""
+    import ast
+    from einops import rearrange, repeat
+    path = os.path.join(REF, "tests/test_flash_attn.py")
+    tree = ast.parse(open(path).read(), filename=path)
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "attn_bias_from_alibi_slopes"]
+    ns = {"torch": torch, "rearrange": rearrange, "repeat": repeat}
+    exec(compile(ast.Module(body=fn, type_ignores=[]), path, "exec"), ns)
+    return ns["attn_bias_from_alibi_slopes"]
 
 
 def c_oracle():
@@ -63,6 +76,7 @@ def c_oracle():
 
 def main():
     fa2, fa3 = import_reference()
+    ref_alibi = import_reference_alibi()
     crun = c_oracle()
     golden = {}
     worst = 0.0
@@ -98,6 +112,11 @@ def main():
             }
             print(f"{name:34s} fp32 err {e1:.2e}  pt err {e2:.1e}  (FA3 oracle, descales, e4m3 P)")
             continue
+        slopes = make_alibi_slopes(c)
+        if slopes is not None:
+            bias = ref_alibi(slopes, c["sq"], c["sk"], qm, km, causal=c["causal"])
+            assert torch.equal(bias, mine.attn_bias_from_alibi_slopes(slopes, c["sq"], c["sk"], qm, km, causal=c["causal"])), name
+            kw["attn_bias"] = bias
         # the reference, three ways: fp32 ("out_ref"), low-precision reordered ("out_pt"), FA3 flavour
         ref_out, ref_attn = fa2.attention_ref(q, k, v, qm, km, **kw)
         ref_pt, _ = fa2.attention_ref(q, k, v, qm, km, **kw, upcast=False, reorder_ops=True)
@@ -118,7 +137,7 @@ def main():
         assert e4 <= 1e-6 if q.dtype == torch.float32 else e4 <= 4e-3, (name, "attention probs", e4)
         worst = max(worst, e1)
         # C fp64 restatement (dense cases only: no padding masks)
-        if qm is None and km is None:
+        if qm is None and km is None and slopes is None:
             scale = q.shape[-1] ** -0.5
             c_out, c_lse = crun(q, k, v, scale, c["causal"], c["window"], c["softcap"])
             e5 = (c_out - ref_out32).abs().max().item()
@@ -139,6 +158,46 @@ def main():
     out_path = os.path.join(ROOT, "tests/golden/attention_ref_golden.pt")
     torch.save(golden, out_path)
     print(f"wrote {out_path} ({os.path.getsize(out_path) / 1e6:.2f} MB), worst fp32 deviation {worst:.2e}")
+
+    # ---- backward fixtures: autograd through the reference oracle (tests/test_flash_attn.py:1071-1105) ----------
+    grads = {}
+    for name, c in GRAD_CASES.items():
+        q, k, v = make_inputs(c)
+        g = make_grad_output(c)
+        qm, km = padding_masks(c)
+        kw = dict(causal=c["causal"], window_size=c["window"], softcap=c["softcap"])
+        slopes = make_alibi_slopes(c)
+        if slopes is not None:
+            kw["attn_bias"] = ref_alibi(slopes, c["sq"], c["sk"], qm, km, causal=c["causal"])
+
+        def run(fn, **extra):
+            ql, kl, vl = (t.clone().requires_grad_(True) for t in (q, k, v))
+            out = fn(ql, kl, vl, qm, km, **kw, **extra)[0]
+            return (out.detach(),) + torch.autograd.grad(out, (ql, kl, vl), g)
+        # The FA2 oracle soft-caps in place (tests/test_util.py:235-238), which autograd rejects; the FA3 oracle
+        # (hopper/test_util.py:294-295, what hopper/test_flash_attn.py differentiates) does not.
+        ref_fn = fa3.attention_ref if c["softcap"] > 0 else fa2.attention_ref
+        ref = run(ref_fn)
+        pt = run(ref_fn, upcast=False, reorder_ops=True)
+        my = run(mine.attention_ref)
+        my_pt = run(mine.attention_ref, upcast=False, reorder_ops=True)
+        for a, b_, what in zip(ref + pt, my + my_pt, ("out", "dq", "dk", "dv") * 2):
+            if c["softcap"] > 0:  # FA3 oracle: q * scale instead of q / sqrt(d) -> 16-bit rounding flips
+                err = (a.float() - b_.float()).abs().max().item()
+                assert err <= 2.0 ** -6 * max(1.0, a.float().abs().max().item()), (name, what, err)
+            else:
+                assert torch.equal(a, b_), (name, what, "restatement autograd differs from the reference's")
+        grads[name] = {
+            "case": {k2: (list(v2) if isinstance(v2, tuple) else v2) for k2, v2 in c.items()},
+            "input_checksum": torch.tensor([checksum(q), checksum(k), checksum(v), checksum(g)], dtype=torch.float64),
+            "out_ref": ref[0], "dq_ref": ref[1], "dk_ref": ref[2], "dv_ref": ref[3],
+            "out_pt": pt[0], "dq_pt": pt[1], "dk_pt": pt[2], "dv_pt": pt[3],
+        }
+        errs = [(pt[i].float() - ref[i].float()).abs().max().item() for i in (1, 2, 3)]
+        print(f"{name:34s} |d*_pt - d*_ref| = {errs[0]:.2e} {errs[1]:.2e} {errs[2]:.2e}")
+    out_path = os.path.join(ROOT, "tests/golden/attention_grad_golden.pt")
+    torch.save(grads, out_path)
+    print(f"wrote {out_path} ({os.path.getsize(out_path) / 1e6:.2f} MB)")
 
 
 if __name__ == "__main__":

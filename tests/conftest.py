@@ -25,3 +25,10 @@ def built_lib():
     from flash_attention_annotated_amd import _lib
     _lib.build()
     return _lib.load()
+
+
+@pytest.fixture(scope="session")
+def golden_grads():
+    """Gradients frozen from the reference's oracle + autograd by oracle/make_golden.py (tensors only)."""
+    import torch
+    return torch.load(os.path.join(ROOT, "tests", "golden", "attention_grad_golden.pt"), weights_only=True)

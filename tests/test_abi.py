@@ -13,20 +13,24 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _header_functions():
-    text = open(os.path.join(ROOT, "include", "fa_fwd.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(fa_\w+)\s*\(", text)))
+    names = set()
+    for header in ("fa_fwd.h", "fa_bwd.h"):
+        text = open(os.path.join(ROOT, "include", header)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b(fa_\w+)\s*\(", text))
+    return sorted(names)
 
 
 def test_header_symbols_all_exported(built_lib):
     names = _header_functions()
     assert set(names) == set(_lib.EXPORTED_SYMBOLS), "binding list and header disagree"
     for n in names:
-        assert hasattr(built_lib, n), f"{n} declared in include/fa_fwd.h but not exported"
+        assert hasattr(built_lib, n), f"{n} declared in include/*.h but not exported"
 
 
 def test_struct_layout_and_version(built_lib):
     assert built_lib.fa_fwd_params_size() == ctypes.sizeof(_lib.FaFwdParams)
+    assert built_lib.fa_bwd_params_size() == ctypes.sizeof(_lib.FaBwdParams)
     assert built_lib.fa_abi_version() == _lib.FA_ABI_VERSION
 
 
@@ -86,3 +90,42 @@ def test_tile_shape(built_lib):
     assert built_lib.fa_fwd_tile_shape(256, _lib.FA_DTYPE_BF16, 1, ctypes.byref(bm), ctypes.byref(bn)) == 0
     assert (bm.value, bn.value) == (128, 64)
     assert built_lib.fa_fwd_tile_shape(300, 0, 0, None, None) == -3
+
+
+def _good_bwd():
+    p = _lib.new_bwd_params()
+    for f in ("q", "k", "v", "o", "dout", "softmax_lse", "dq", "dk", "dv", "softmax_d"):
+        setattr(p, f, 0x10000)
+    p.b, p.seqlen_q, p.seqlen_k, p.h, p.h_k, p.d = 2, 128, 128, 4, 2, 64
+    p.dtype = _lib.FA_DTYPE_BF16
+    for t in ("q", "o", "do", "dq"):
+        setattr(p, f"{t}_row_stride", 4 * 64)
+        setattr(p, f"{t}_head_stride", 64)
+        setattr(p, f"{t}_batch_stride", 128 * 4 * 64)
+    for t in ("k", "v", "dk", "dv"):
+        setattr(p, f"{t}_row_stride", 2 * 64)
+        setattr(p, f"{t}_head_stride", 64)
+        setattr(p, f"{t}_batch_stride", 128 * 2 * 64)
+    p.softmax_d_row_len = 128
+    p.softmax_scale = 0.125
+    p.window_size_left = p.window_size_right = -1
+    return p
+
+
+@pytest.mark.parametrize("mutate,code", [
+    (lambda p: None, 0),
+    (lambda p: setattr(p, "dtype", 2), -2),                 # no fp8 backward
+    (lambda p: setattr(p, "d", 264), -3),
+    (lambda p: setattr(p, "h_k", 3), -4),
+    (lambda p: setattr(p, "dout", 0), -1),
+    (lambda p: setattr(p, "dk_row_stride", 100), -6),
+    (lambda p: setattr(p, "softmax_d_row_len", 64), -5),    # shorter than seqlen_q
+    (lambda p: setattr(p, "abi_version", 1), -9),
+])
+def test_bwd_validate(built_lib, mutate, code):
+    """include/fa_bwd.h: the checks of mha_bwd (csrc/flash_attn/flash_api.cpp:803-870) as status codes."""
+    p = _good_bwd()
+    mutate(p)
+    assert built_lib.fa_bwd_validate(ctypes.byref(p)) == code
+    if code != 0:
+        assert built_lib.fa_bwd(ctypes.byref(p), None) == code

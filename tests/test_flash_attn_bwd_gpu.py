@@ -1,0 +1,223 @@
+"""GPU parity tests of the HIP backward (include/fa_bwd.h) through the autograd surface of the public API.
+
+Tolerance contract of the reference (tests/test_flash_attn.py:1129-1132, 1446-1451; hopper/test_flash_attn.py:262-286):
+    |dX - dX_ref|max <= 3 * |dX_pt - dX_ref|max  (+ atol)
+where dX_ref differentiates the oracle in fp32 and dX_pt differentiates it in the inputs' precision; atol is the FA3
+form 2 * |(dX_ref + 0.3 - 0.3) - dX_ref|max.  Floating point; the bound is stated in _check_grads.
+"""
+import math
+
+import pytest
+import torch
+
+from oracle import attention_ref as oracle
+from oracle.cases import GRAD_CASES, checksum, make_alibi_slopes, make_grad_output, make_inputs, padding_masks
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _api():
+    import flash_attention_annotated_amd as fa
+    return fa
+
+
+def _bound(ref, pt):
+    ref = ref.float()
+    atol = 2 * (ref + 0.3 - 0.3 - ref).abs().max().item()
+    return 3 * (pt.float() - ref).abs().max().item() + atol + 1e-5
+
+
+def _check_grads(got, ref, pt, what=""):
+    for name, g, r, p in zip(("dq", "dk", "dv"), got, ref, pt):
+        g = g.float().cpu()
+        assert torch.isfinite(g).all(), f"{what} {name}: non-finite"
+        err = (g - r.float()).abs().max().item()
+        bound = _bound(r, p)
+        assert err <= bound, f"{what} {name}: max err {err:.3e} > bound {bound:.3e}"
+
+
+def _oracle_grads(q, k, v, g, qm=None, km=None, **kw):
+    def run(**extra):
+        ql, kl, vl = (t.clone().requires_grad_(True) for t in (q, k, v))
+        out = oracle.attention_ref(ql, kl, vl, qm, km, **kw, **extra)[0]
+        return torch.autograd.grad(out, (ql, kl, vl), g)
+    return run(), run(upcast=False, reorder_ops=True)
+
+
+def _hip_grads(fn, q, k, v, g, **kw):
+    ql, kl, vl = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
+    out = fn(ql, kl, vl, **kw)
+    return out, torch.autograd.grad(out, (ql, kl, vl), g.to(DEV))
+
+
+@pytest.mark.parametrize("name", list(GRAD_CASES))
+def test_golden_grads(name, golden_grads):
+    """HIP dq/dk/dv vs the gradients frozen from the reference's oracle (oracle/make_golden.py)."""
+    fa = _api()
+    c, gold = GRAD_CASES[name], golden_grads[name]
+    q, k, v = make_inputs(c)
+    g = make_grad_output(c)
+    assert abs(checksum(g) - gold["input_checksum"][3].item()) < 1e-6
+    qm, km = padding_masks(c)
+    kw = dict(causal=c["causal"], window_size=c["window"], softcap=c["softcap"])
+    slopes = make_alibi_slopes(c)
+    if slopes is not None:
+        kw["alibi_slopes"] = slopes.to(DEV)
+    if qm is None:
+        _, got = _hip_grads(fa.flash_attn_func, q, k, v, g, **kw)
+    else:
+        from flash_attention_annotated_amd.bert_padding import pad_input, unpad_input
+        qu, iq, cuq, mq, _ = unpad_input(q, qm)
+        ku, ik, cuk, mk, _ = unpad_input(k, km)
+        vu = unpad_input(v, km)[0]
+        gu = unpad_input(g, qm)[0]
+        _, gu_ = _hip_grads(lambda a, b, c_, **kk: fa.flash_attn_varlen_func(a, b, c_, cuq.to(DEV), cuk.to(DEV), mq, mk, **kk),
+                            qu, ku, vu, gu, **kw)
+        got = (pad_input(gu_[0].cpu(), iq, c["b"], c["sq"]), pad_input(gu_[1].cpu(), ik, c["b"], c["sk"]),
+               pad_input(gu_[2].cpu(), ik, c["b"], c["sk"]))
+        # padded positions carry no gradient in the oracle either (masked_fill of the output / -inf scores)
+    _check_grads(got, (gold["dq_ref"], gold["dk_ref"], gold["dv_ref"]), (gold["dq_pt"], gold["dk_pt"], gold["dv_pt"]), name)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("d", [64, 128])
+@pytest.mark.parametrize("sq,sk", [(1, 147), (113, 203), (128, 217), (203, 113), (256, 256), (384, 256), (512, 512),
+                                   (1023, 1024)])
+@pytest.mark.parametrize("mha_type", ["mha", "gqa", "mqa"])
+def test_dense_grads(sq, sk, d, causal, dtype, mha_type):
+    """Shape matrix of tests/test_flash_attn.py:878-919 in miniature, gradients."""
+    if mha_type != "mha" and (sq, sk) not in [(113, 203), (512, 512)]:
+        pytest.skip("gqa/mqa on a subset of shapes")
+    fa = _api()
+    torch.manual_seed(0)
+    b, h = 2, 4
+    hk = {"mha": 4, "gqa": 2, "mqa": 1}[mha_type]
+    q = torch.randn(b, sq, h, d, dtype=dtype)
+    k = torch.randn(b, sk, hk, d, dtype=dtype)
+    v = torch.randn(b, sk, hk, d, dtype=dtype)
+    g = torch.randn(b, sq, h, d, dtype=dtype)
+    out, got = _hip_grads(fa.flash_attn_func, q, k, v, g, causal=causal)
+    ref, pt = _oracle_grads(q, k, v, g, causal=causal)
+    _check_grads(got, ref, pt, f"{sq}x{sk} d{d} causal={causal} {mha_type}")
+
+
+@pytest.mark.parametrize("d", [32, 40, 59, 96, 111, 160, 192, 224, 256])
+def test_head_dims_grads(d):
+    fa = _api()
+    torch.manual_seed(1)
+    q = torch.randn(1, 150, 4, d, dtype=torch.bfloat16)
+    k = torch.randn(1, 200, 2, d, dtype=torch.bfloat16)
+    v = torch.randn(1, 200, 2, d, dtype=torch.bfloat16)
+    g = torch.randn(1, 150, 4, d, dtype=torch.bfloat16)
+    _, got = _hip_grads(fa.flash_attn_func, q, k, v, g, causal=True)
+    assert got[0].shape == q.shape and got[1].shape == k.shape
+    ref, pt = _oracle_grads(q, k, v, g, causal=True)
+    _check_grads(got, ref, pt, f"d={d}")
+
+
+@pytest.mark.parametrize("window", [(64, 0), (16, 16), (0, 32), (-1, 17)])
+@pytest.mark.parametrize("sq,sk", [(113, 203), (300, 300), (400, 150)])
+def test_local_window_grads(sq, sk, window):
+    fa = _api()
+    torch.manual_seed(2)
+    q = torch.randn(2, sq, 4, 64, dtype=torch.bfloat16)
+    k = torch.randn(2, sk, 2, 64, dtype=torch.bfloat16)
+    v = torch.randn(2, sk, 2, 64, dtype=torch.bfloat16)
+    g = torch.randn(2, sq, 4, 64, dtype=torch.bfloat16)
+    _, got = _hip_grads(fa.flash_attn_func, q, k, v, g, window_size=window)
+    ref, pt = _oracle_grads(q, k, v, g, window_size=window)
+    _check_grads(got, ref, pt, f"window={window}")
+
+
+def test_alibi_and_softcap_grads():
+    fa = _api()
+    torch.manual_seed(3)
+    q = torch.randn(2, 200, 4, 64, dtype=torch.bfloat16) * 3
+    k = torch.randn(2, 260, 2, 64, dtype=torch.bfloat16)
+    v = torch.randn(2, 260, 2, 64, dtype=torch.bfloat16)
+    g = torch.randn(2, 200, 4, 64, dtype=torch.bfloat16)
+    slopes = torch.rand(2, 4) * 0.3
+    bias = oracle.attn_bias_from_alibi_slopes(slopes, 200, 260)
+    _, got = _hip_grads(fa.flash_attn_func, q, k, v, g, alibi_slopes=slopes.to(DEV))
+    ref, pt = _oracle_grads(q, k, v, g, attn_bias=bias)
+    _check_grads(got, ref, pt, "alibi")
+    _, got = _hip_grads(fa.flash_attn_func, q, k, v, g, softcap=15.0, causal=True)
+    ref, pt = _oracle_grads(q, k, v, g, softcap=15.0, causal=True)
+    _check_grads(got, ref, pt, "softcap")
+
+
+def test_varlen_grads_do_not_leak_across_sequences():
+    """Packed ragged batch, causal, GQA: gradients vs the per-sequence oracle; a neighbour's rows are untouched."""
+    fa = _api()
+    torch.manual_seed(4)
+    lens_q, lens_k = [70, 1, 128, 33], [90, 64, 128, 200]
+    h, hk, d = 4, 2, 64
+    cuq = torch.tensor([0] + list(torch.tensor(lens_q).cumsum(0)), dtype=torch.int32)
+    cuk = torch.tensor([0] + list(torch.tensor(lens_k).cumsum(0)), dtype=torch.int32)
+    q = torch.randn(sum(lens_q), h, d, dtype=torch.float16)
+    k = torch.randn(sum(lens_k), hk, d, dtype=torch.float16)
+    v = torch.randn(sum(lens_k), hk, d, dtype=torch.float16)
+    g = torch.randn(sum(lens_q), h, d, dtype=torch.float16)
+    fn = lambda a, b, c_: fa.flash_attn_varlen_func(a, b, c_, cuq.to(DEV), cuk.to(DEV), max(lens_q), max(lens_k), causal=True)
+    _, got = _hip_grads(fn, q, k, v, g)
+    for i in range(len(lens_q)):
+        qs, ks = slice(cuq[i], cuq[i + 1]), slice(cuk[i], cuk[i + 1])
+        ref, pt = _oracle_grads(q[qs][None], k[ks][None], v[ks][None], g[qs][None], causal=True)
+        _check_grads((got[0][qs][None], got[1][ks][None], got[2][ks][None]), ref, pt, f"seq {i}")
+
+
+def test_backward_is_deterministic_and_packed_qkv_views_work():
+    """One producer per gradient element: reruns are bit-identical (the reference needs deterministic=True for that,
+    tests/test_flash_attn.py:2455-2519).  Inputs are strided views of one packed tensor."""
+    fa = _api()
+    torch.manual_seed(5)
+    qkv = torch.randn(2, 300, 3, 4, 128, dtype=torch.bfloat16, device=DEV, requires_grad=True)
+    g = torch.randn(2, 300, 4, 128, dtype=torch.bfloat16, device=DEV)
+    out = fa.flash_attn_qkvpacked_func(qkv, causal=True)
+    (d0,) = torch.autograd.grad(out, qkv, g, retain_graph=True)
+    for _ in range(3):
+        (d1,) = torch.autograd.grad(out, qkv, g, retain_graph=True)
+        assert torch.equal(d0, d1)
+    q, k, v = (qkv.detach().cpu()[:, :, i] for i in range(3))
+    ref, pt = _oracle_grads(q, k, v, g.cpu(), causal=True)
+    _check_grads(tuple(d0[:, :, i] for i in range(3)), ref, pt, "qkvpacked")
+
+
+def test_full_size_gradient_properties():
+    """BASELINE C2-shaped problem (b1 instead of b4): size-independent properties.
+    (1) dV is linear in dO; (2) sum_j dS_ij = 0 for every row => dQ is unchanged when a constant vector is added to
+    every key (softmax shift invariance), checked through d<q, dq>/... the cheap form: sum over d of q*dq equals
+    sum over d of k*dk summed per head (both equal sum_ij dS_ij S_ij / scale)."""
+    fa = _api()
+    torch.manual_seed(6)
+    b, s, h, d = 1, 8192, 16, 128
+    q = torch.randn(b, s, h, d, dtype=torch.bfloat16, device=DEV, requires_grad=True)
+    k = torch.randn(b, s, h, d, dtype=torch.bfloat16, device=DEV, requires_grad=True)
+    v = torch.randn(b, s, h, d, dtype=torch.bfloat16, device=DEV, requires_grad=True)
+    g = torch.randn(b, s, h, d, dtype=torch.bfloat16, device=DEV)
+    out = fa.flash_attn_func(q, k, v)
+    dq, dk, dv = torch.autograd.grad(out, (q, k, v), g, retain_graph=True)
+    _, _, dv2 = torch.autograd.grad(out, (q, k, v), 2 * g)
+    assert (dv2.float() - 2 * dv.float()).abs().max().item() <= 2e-2 * dv.float().abs().max().item()
+    a = (q.float() * dq.float()).sum(dim=(1, 3))
+    c = (k.float() * dk.float()).sum(dim=(1, 3))
+    scale = max(a.abs().max().item(), 1.0)
+    assert (a - c).abs().max().item() <= 2e-2 * scale + 1.0, ((a - c).abs().max().item(), scale)
+    # columns of P sum the incoming gradient: sum_j dV_j = sum_i dO_i (rows of P sum to 1)
+    lhs, rhs = dv.float().sum(dim=1), g.float().sum(dim=1)
+    assert (lhs - rhs).abs().max().item() <= 2e-2 * rhs.abs().max().item() + 0.5
+
+
+def test_bwd_errors_are_the_reference_messages():
+    import flash_attention_annotated_amd.flash_attn_2_cuda as m
+    q = torch.randn(1, 8, 2, 64, dtype=torch.bfloat16, device=DEV)
+    lse = torch.zeros(1, 2, 8, device=DEV)
+    with pytest.raises(RuntimeError, match="query and dout must have the same dtype"):
+        m.bwd(q.half(), q, q, q, q, lse, None, None, None, None, 0.0, 0.125, False, -1, -1, 0.0, False, None, None)
+    with pytest.raises(RuntimeError, match="does not support dropout"):
+        m.bwd(q, q, q, q, q, lse, None, None, None, None, 0.1, 0.125, False, -1, -1, 0.0, False, None, None)
+    with pytest.raises(RuntimeError, match="dq must have shape"):
+        m.bwd(q, q, q, q, q, lse, q[:, :4], None, None, None, 0.0, 0.125, False, -1, -1, 0.0, False, None, None)

@@ -13,7 +13,7 @@ import pytest
 import torch
 
 from oracle import attention_ref as oracle
-from oracle.cases import CASES, checksum, make_inputs, padding_masks
+from oracle.cases import CASES, checksum, make_alibi_slopes, make_inputs, padding_masks
 
 pytestmark = pytest.mark.gpu
 
@@ -65,9 +65,17 @@ def test_golden_cases(name, golden):
     qm, km = padding_masks(c)
     stride = c["store_row_stride"]
     kw = dict(causal=c["causal"], window_size=c["window"], softcap=c["softcap"])
+    slopes = make_alibi_slopes(c)
+    lse_ref = g["lse"]
+    if slopes is not None:
+        kw["alibi_slopes"] = slopes.to(DEV)
+        # the kernel's LSE carries the general bias -slope*|i + sk - sq - j| (include/fa_fwd.h); the frozen causal
+        # fixture was made with the reference's causal shortcut slope*(j - sk + 1), a per-row constant apart
+        bias = oracle.attn_bias_from_alibi_slopes(slopes, c["sq"], c["sk"], qm, km, causal=False)
+        lse_ref = oracle.attention_ref(q, k, v, qm, km, attn_bias=bias, causal=c["causal"], window_size=c["window"],
+                                       softcap=c["softcap"], return_lse=True)[2][:, :, ::stride]
     if qm is None:
         out, lse, _ = fa.flash_attn_func(q.to(DEV), k.to(DEV), v.to(DEV), **kw, return_attn_probs=True)
-        out_ref_full, out_pt_full, lse_ref = _dense_ref(q, k, v, **kw)
     else:
         from flash_attention_annotated_amd.bert_padding import pad_input, unpad_input
         qu, iq, cuq, mq, _ = unpad_input(q, qm)
@@ -78,7 +86,59 @@ def test_golden_cases(name, golden):
         lse = None
     err, bound = _check(out[:, ::stride], g["out_ref_fp32"], g["out_pt"], name)
     if lse is not None:
-        _check_lse(lse[:, :, ::stride], g["lse"])
+        _check_lse(lse[:, :, ::stride], lse_ref)
+
+
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("sq,sk,d", [(113, 203, 64), (512, 512, 128), (1024, 1023, 64), (203, 113, 256), (2048, 2048, 128)])
+@pytest.mark.parametrize("per_batch", [False, True])
+def test_alibi(sq, sk, d, causal, per_batch):
+    """ALiBi slopes (h) or (b, h), rand * 0.3 as tests/test_flash_attn.py:936-940; oracle bias from
+    attn_bias_from_alibi_slopes (:29-56, restated in oracle/ and pinned to the reference by make_golden.py)."""
+    fa = _api()
+    torch.manual_seed(11)
+    b, h, hk = 2, 4, 2
+    q = torch.randn(b, sq, h, d, dtype=torch.bfloat16)
+    k = torch.randn(b, sk, hk, d, dtype=torch.bfloat16)
+    v = torch.randn(b, sk, hk, d, dtype=torch.bfloat16)
+    slopes = torch.rand(b, h, dtype=torch.float32) * 0.3
+    if not per_batch:
+        slopes = slopes[:1].expand(b, h).contiguous()
+    arg = slopes if per_batch else slopes[0].contiguous()
+    out, lse, _ = fa.flash_attn_func(q.to(DEV), k.to(DEV), v.to(DEV), causal=causal, alibi_slopes=arg.to(DEV),
+                                     return_attn_probs=True)
+    bias = oracle.attn_bias_from_alibi_slopes(slopes, sq, sk, causal=False)
+    out_ref, out_pt, lse_ref = _dense_ref(q, k, v, causal=causal, attn_bias=bias)
+    _check(out, out_ref, out_pt, f"alibi {sq}x{sk} d{d} causal={causal}")
+    _check_lse(lse, lse_ref)
+    if causal:  # the reference's causal shortcut bias gives the same output
+        bias_c = oracle.attn_bias_from_alibi_slopes(slopes, sq, sk, causal=True)
+        out_ref_c, out_pt_c, _ = _dense_ref(q, k, v, causal=True, attn_bias=bias_c)
+        _check(out, out_ref_c, out_pt_c, "alibi causal shortcut")
+
+
+def test_alibi_varlen_softcap():
+    """ALiBi through the varlen entry point (per-sequence sk - sq shift) together with softcap."""
+    fa = _api()
+    from flash_attention_annotated_amd.bert_padding import pad_input, unpad_input
+    torch.manual_seed(12)
+    b, sq, sk, h, d = 3, 150, 190, 4, 64
+    q = torch.randn(b, sq, h, d, dtype=torch.float16) * 4
+    k = torch.randn(b, sk, h, d, dtype=torch.float16)
+    v = torch.randn(b, sk, h, d, dtype=torch.float16)
+    qm = torch.arange(sq).view(1, -1) < torch.tensor([[150], [131], [140]])
+    km = torch.arange(sk).view(1, -1) < torch.tensor([[171], [190], [175]])
+    slopes = torch.rand(b, h, dtype=torch.float32) * 0.3
+    qu, iq, cuq, mq, _ = unpad_input(q, qm)
+    ku, ik, cuk, mk, _ = unpad_input(k, km)
+    vu = unpad_input(v, km)[0]
+    out_u = fa.flash_attn_varlen_func(qu.to(DEV), ku.to(DEV), vu.to(DEV), cuq.to(DEV), cuk.to(DEV), mq, mk,
+                                      softcap=20.0, alibi_slopes=slopes.to(DEV))
+    out = pad_input(out_u.cpu(), iq, b, sq)
+    bias = oracle.attn_bias_from_alibi_slopes(slopes, sq, sk, qm, km)
+    out_ref, _ = oracle.attention_ref(q, k, v, qm, km, attn_bias=bias, softcap=20.0)
+    out_pt, _ = oracle.attention_ref(q, k, v, qm, km, attn_bias=bias, softcap=20.0, upcast=False, reorder_ops=True)
+    _check(out, out_ref, out_pt, "alibi varlen softcap")
 
 
 SHAPES = [(1, 1), (1, 147), (64, 128), (113, 203), (128, 217), (203, 113), (256, 256), (257, 1), (384, 256),

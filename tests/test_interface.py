@@ -39,9 +39,10 @@ def test_extension_module_surface():
     assert len(inspect.signature(flash_attn_2_cuda.varlen_fwd).parameters) == 21
     import flash_attn_2_cuda as top_level_alias  # the name the reference imports
     assert top_level_alias.fwd is flash_attn_2_cuda.fwd
-    for f in (flash_attn_2_cuda.bwd, flash_attn_2_cuda.varlen_bwd, flash_attn_2_cuda.fwd_kvcache):
-        with pytest.raises(RuntimeError, match="not built"):
-            f()
+    assert len(inspect.signature(flash_attn_2_cuda.bwd).parameters) == 19          # :767-786
+    assert len(inspect.signature(flash_attn_2_cuda.varlen_bwd).parameters) == 24   # :973-997
+    with pytest.raises(RuntimeError, match="not built"):
+        flash_attn_2_cuda.fwd_kvcache()
 
 
 def test_no_cpu_fallback():

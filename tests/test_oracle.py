@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from oracle import attention_ref as oracle
-from oracle.cases import CASES, checksum, make_descales, make_inputs, padding_masks
+from oracle.cases import CASES, checksum, make_alibi_slopes, make_descales, make_inputs, padding_masks
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -29,6 +29,9 @@ def test_oracle_reproduces_reference_golden(name, golden):
         qd, kd, vd = make_descales(c)
         kw.update(q_descale=qd, k_descale=kd, v_descale=vd)
         ptkw = dict(intermediate_dtype=torch.float8_e4m3fn)
+    slopes = make_alibi_slopes(c)
+    if slopes is not None:  # bias built exactly as the reference's tests build it (causal shortcut included)
+        kw["attn_bias"] = oracle.attn_bias_from_alibi_slopes(slopes, c["sq"], c["sk"], qm, km, causal=c["causal"])
     out32, _ = oracle.attention_ref(q.float(), k.float(), v.float(), qm, km, **kw)
     out_pt, _ = oracle.attention_ref(q, k, v, qm, km, **kw, **ptkw, upcast=False, reorder_ops=True)
     # fp32 math: same op order as the reference -> agreement to rounding (bit-identical in the build container)
@@ -115,3 +118,28 @@ def test_varlen_oracle_matches_padded_oracle():
     for i in range(b):
         assert (out_u[cq[i]:cq[i + 1]] - ref[i, :lens_q[i]]).abs().max().item() <= 1e-6
     assert lse_u.shape == (h, 33)
+
+
+@pytest.mark.parametrize("name", list(__import__("oracle.cases", fromlist=["GRAD_CASES"]).GRAD_CASES))
+def test_oracle_autograd_reproduces_reference_gradients(name, golden_grads):
+    """tests/golden/attention_grad_golden.pt: dq/dk/dv obtained by differentiating the reference's own attention_ref
+    (tests/test_flash_attn.py:1071-1105); autograd through the restatement must reproduce them."""
+    from oracle.cases import GRAD_CASES, make_grad_output
+    c, gold = GRAD_CASES[name], golden_grads[name]
+    q, k, v = make_inputs(c)
+    g = make_grad_output(c)
+    for t, want in zip((q, k, v, g), gold["input_checksum"].tolist()):
+        assert abs(checksum(t) - want) <= 1e-6 * max(1.0, abs(want))
+    qm, km = padding_masks(c)
+    kw = dict(causal=c["causal"], window_size=tuple(c["window"]), softcap=c["softcap"])
+    slopes = make_alibi_slopes(c)
+    if slopes is not None:
+        kw["attn_bias"] = oracle.attn_bias_from_alibi_slopes(slopes, c["sq"], c["sk"], qm, km, causal=c["causal"])
+    for tag, extra in (("ref", {}), ("pt", dict(upcast=False, reorder_ops=True))):
+        ql, kl, vl = (t.clone().requires_grad_(True) for t in (q, k, v))
+        out = oracle.attention_ref(ql, kl, vl, qm, km, **kw, **extra)[0]
+        grads = torch.autograd.grad(out, (ql, kl, vl), g)
+        for nm, got in zip(("dq", "dk", "dv"), grads):
+            want = gold[f"{nm}_{tag}"].float()
+            tol = 2.0 ** -6 * max(1.0, want.abs().max().item())  # a few 16-bit ulps across hosts / the FA3-oracle case
+            assert (got.float() - want).abs().max().item() <= tol, (tag, nm)
