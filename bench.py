@@ -33,6 +33,10 @@ WORKLOADS = {
     "c4": ("C4 varlen GQA hq32 hkv8 d128 lens 8192..1024 bf16 non-causal", 8, 32, 8, 8192, 128, False,
            [8192, 7168, 6144, 5120, 4096, 3072, 2048, 1024]),
     # C5: fp8 e4m3 inputs (bf16 output), descales = 1; global batch 32 strong-scaled in BASELINE.md -> here 4 per GPU
+    # backward of C2 / C3: dq, dk, dv from (dout, q, k, v, out, lse); FLOPs = 2.5 x forward
+    # (benchmarks/benchmark_flash_attention.py:27-30 mode="bwd")
+    "c2_bwd": ("C2 backward b4 h16 d128 s8192 bf16 non-causal", 4, 16, 16, 8192, 128, False, None),
+    "c3_bwd": ("C3 backward b4 h16 d128 s16384 bf16 causal", 4, 16, 16, 16384, 128, True, None),
     "c5": ("C5 fp8 e4m3 b4 h16 d128 s8192 non-causal (fp8 storage, exact bf16 expansion pass + bf16 MFMA)", 4, 16, 16,
            8192, 128, False, None),
 }
@@ -44,12 +48,16 @@ def flops_of(w):
         f = sum(4 * h * d * L * L for L in lens)
     else:
         f = 4 * b * h * s * s * d
+    if w[0].split()[1] == "backward":
+        f = f * 5 // 2
     return f // 2 if causal else f
 
 
 def algorithmic_bytes(w):
     _, b, h, hk, s, d, causal, lens = w
     rows = sum(lens) if lens is not None else b * s
+    if w[0].split()[1] == "backward":  # read Q,K,V,O,dO + LSE; write dQ,dK,dV (+ D written and read once)
+        return 2 * (4 * rows * h * d + 4 * rows * hk * d) + 4 * rows * h * 3
     return 2 * (2 * rows * h * d + 2 * rows * hk * d) + 4 * rows * h  # Q+O, K+V (bf16) + LSE (fp32)
 
 
@@ -163,7 +171,18 @@ def main():
     w = WORKLOADS[args.workload]
     (q, k, v), extra = make_inputs(w, device, seed=rank)  # each rank: its own batch shard, already in HBM
 
+    bwd_state = None
+    if args.workload.endswith("_bwd"):
+        from flash_attention_annotated_amd import flash_attn_2_cuda as ext
+        scale = w[5] ** -0.5
+        out, lse, _, _ = ext.fwd(q, k, v, None, None, 0.0, scale, w[6], -1, -1, 0.0, False, None)
+        g = torch.randn(q.shape, device=device, dtype=q.dtype, generator=torch.Generator(device=device).manual_seed(100 + rank))
+        bwd_state = (ext, g, out, lse, torch.empty_like(q), torch.empty_like(k), torch.empty_like(v), scale)
+
     def step():
+        if bwd_state is not None:
+            ext, g, out, lse, dq, dk, dv, scale = bwd_state
+            return ext.bwd(g, q, k, v, out, lse, dq, dk, dv, None, 0.0, scale, w[6], -1, -1, 0.0, False, None, None)
         if "fp8" in extra:
             from flash_attention_annotated_amd import hopper_interface as fa3
             d1 = extra["descale"]
