@@ -41,6 +41,10 @@ int64_t unit_grid(int64_t tiles, int blocks) {
 
 template <typename T, int D, bool SOFTCAP>
 int run_bwd(fa::BParams bp, int rows_q_max, int rows_k_max, hipStream_t stream) {
+    // 32-wide blocks per wave (every LDS fragment feeds NB MFMAs): two wherever accumulators + resident operands fit
+    // the 512-register budget of a lone wave.  dQ: 2 for D <= 128; dK/dV (two accumulator sets + K and V): 2 for D = 64.
+    constexpr int NBQ = D <= 128 ? 2 : 1;
+    constexpr int NBK = D <= 64 ? 2 : 1;
     // 1. D = rowsum(dO * O)
     {
         const int64_t rows = bp.cu_seqlens_q ? (int64_t)bp.total_q : (int64_t)bp.b * bp.seqlen_q;
@@ -54,7 +58,7 @@ int run_bwd(fa::BParams bp, int rows_q_max, int rows_k_max, hipStream_t stream) 
     // 2. dK, dV
     {
         static std::atomic<bool> attr{false};
-        bp.num_blocks = (rows_k_max + 127) / 128;
+        bp.num_blocks = (rows_k_max + 128 * NBK - 1) / (128 * NBK);
         const int64_t tiles = (int64_t)bp.num_blocks * bp.h_k * bp.b;
         if (tiles > 0x7fffffff) return FA_ERR_BAD_SHAPE;
         if (tiles > 0) {
@@ -62,14 +66,14 @@ int run_bwd(fa::BParams bp, int rows_q_max, int rows_k_max, hipStream_t stream) 
             const int64_t grid = unit_grid(tiles, bp.num_blocks);
             if (grid > 0x7fffffff) return FA_ERR_BAD_SHAPE;
             bp.grid = (int32_t)grid;
-            const int st = launch_kernel(fa::bwd_dkdv_kernel<T, D, SOFTCAP>, fa::smem_bytes_dkdv<D>(), attr, bp.grid, 256, bp, stream);
+            const int st = launch_kernel(fa::bwd_dkdv_kernel<T, D, NBK, SOFTCAP>, fa::smem_bytes_dkdv<D>(), attr, bp.grid, 256, bp, stream);
             if (st != FA_OK) return st;
         }
     }
     // 3. dQ
     {
         static std::atomic<bool> attr{false};
-        bp.num_blocks = (rows_q_max + 127) / 128;
+        bp.num_blocks = (rows_q_max + 128 * NBQ - 1) / (128 * NBQ);
         const int64_t tiles = (int64_t)bp.num_blocks * bp.h * bp.b;
         if (tiles > 0x7fffffff) return FA_ERR_BAD_SHAPE;
         if (tiles > 0) {
@@ -77,7 +81,7 @@ int run_bwd(fa::BParams bp, int rows_q_max, int rows_k_max, hipStream_t stream) 
             const int64_t grid = unit_grid(tiles, bp.num_blocks);
             if (grid > 0x7fffffff) return FA_ERR_BAD_SHAPE;
             bp.grid = (int32_t)grid;
-            const int st = launch_kernel(fa::bwd_dq_kernel<T, D, SOFTCAP>, fa::smem_bytes_dq<D>(), attr, bp.grid, 256, bp, stream);
+            const int st = launch_kernel(fa::bwd_dq_kernel<T, D, NBQ, SOFTCAP>, fa::smem_bytes_dq<D>(), attr, bp.grid, 256, bp, stream);
             if (st != FA_OK) return st;
         }
     }

@@ -23,9 +23,46 @@
 //     the same K tile).
 #pragma once
 
+#include <type_traits>
+
 #include "fa_fwd_kernel.h"
+#include "fa_fwd_kernel_w64.h"  // Mfma<T>: inline-asm MFMAs with explicit register classes
 
 namespace fa {
+
+// Score-tile MFMAs whose B operand stays in arch VGPRs (used where the AGPR half is full of accumulators);
+// Mfma<T>::s_first / s_acc take B from AGPRs.  hipcc pads no hazards around these: callers drain before VALU reads.
+template <typename T> struct BMfma;
+template <> struct BMfma<__bf16> {
+    static __device__ __forceinline__ void s_first_v(f32x16 &d, u32x4 a, u32x4 b) {
+        asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b));
+    }
+    static __device__ __forceinline__ void s_acc_v(f32x16 &d, u32x4 a, u32x4 b) {
+        asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
+    }
+};
+template <> struct BMfma<_Float16> {
+    static __device__ __forceinline__ void s_first_v(f32x16 &d, u32x4 a, u32x4 b) {
+        asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b));
+    }
+    static __device__ __forceinline__ void s_acc_v(f32x16 &d, u32x4 a, u32x4 b) {
+        asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
+    }
+};
+// asm MFMA results -> VALU readers: 11+ wait states, with the tiles as operands so nothing is scheduled across
+template <int NB>
+__device__ __forceinline__ void drain_tiles(f32x16 (&a)[NB], f32x16 (&b)[NB]) {
+    if constexpr (NB == 2) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]));
+    else asm volatile("s_nop 15\n\ts_nop 7" : "+v"(a[0]), "+v"(b[0]));
+}
+template <int N>
+__device__ __forceinline__ void drain_acc(f32x16 (&a)[N]) {
+    static_assert(N == 2 || N == 4 || N == 8, "accumulator tiles per array");
+    if constexpr (N == 2) asm volatile("s_nop 15\n\ts_nop 7" : "+a"(a[0]), "+a"(a[1]));
+    else if constexpr (N == 4) asm volatile("s_nop 15\n\ts_nop 7" : "+a"(a[0]), "+a"(a[1]), "+a"(a[2]), "+a"(a[3]));
+    else asm volatile("s_nop 15\n\ts_nop 7" : "+a"(a[0]), "+a"(a[1]), "+a"(a[2]), "+a"(a[3]), "+a"(a[4]), "+a"(a[5]),
+                      "+a"(a[6]), "+a"(a[7]));
+}
 
 struct BParams {
     const void *q, *k, *v, *o, *dout;
@@ -165,29 +202,33 @@ __global__ __launch_bounds__(256) void bwd_dot_kernel(const BParams p) {
 }
 
 // Elementwise core shared by both kernels: from raw score x and dP to (P, dS) for one (query i, key j).
-template <bool SOFTCAP>
+// `visible` is only looked at when MASK (boundary tiles); rows past the end of q carry LSE = +inf, i.e. P = 0.
+template <bool SOFTCAP, bool MASK>
 __device__ __forceinline__ void bwd_point(const BParams &p, float x, float dp, float lse2, float dsum, float alibi2,
                                           int rel /* i + sk - sq - j */, bool visible, float &pv, float &ds) {
     float t = 0.f, sl;
     if constexpr (SOFTCAP) {
         t = fast_tanh(x * p.softcap_pre);
-        sl = t * p.scale_log2;
+        sl = t * p.scale_log2 - lse2;
     } else {
-        sl = x * p.scale_log2;
+        sl = x * p.scale_log2 - lse2;
     }
     if (p.alibi) sl -= alibi2 * fabsf((float)rel);
-    pv = visible ? __builtin_amdgcn_exp2f(sl - lse2) : 0.f;
+    pv = __builtin_amdgcn_exp2f(sl);
+    if constexpr (MASK) pv = visible ? pv : 0.f;
     ds = pv * (dp - dsum);
     if constexpr (SOFTCAP) ds *= (1.f - t * t);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// dK / dV
+// dK / dV.  NB = 32-key blocks per wave: every Q / dO / Q^T / dO^T fragment read from LDS feeds NB MFMAs (the
+// one-block form moves 1 KiB of LDS per MFMA, which is the LDS bandwidth limit of the CU).
 // ------------------------------------------------------------------------------------------------------------------
-template <typename T, int D, bool SOFTCAP>
+template <typename T, int D, int NB, bool SOFTCAP>
 __global__ __launch_bounds__(256, 1) void bwd_dkdv_kernel(const BParams p) {
     constexpr int NT = 256;
-    constexpr int BLOCK_K = 128;               // keys per workgroup (32 per wave)
+    constexpr int WKEYS = 32 * NB;             // keys per wave
+    constexpr int BLOCK_K = 4 * WKEYS;         // keys per workgroup
     constexpr int BM = 64;                     // query rows per streamed tile
     constexpr int KSTEPS = D / 16;
     constexpr int DBLOCKS = D / 32;
@@ -209,6 +250,11 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_kernel(const BParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hh = lane >> 5;
     const int i16 = lane & 15, g1 = (lane >> 4) & 1;
+    // lane parts of the LDS read addresses; everything else is an immediate or one XOR (lds_off's swizzle only
+    // looks at the low 4 row bits, and chunk bits above the swizzle width pass through the XOR): see fa_fwd_kernel_w64.h
+    constexpr int ROWB = D * 2;
+    const int kbase = lds_off<D>(r, hh);                                                        // ^ 32*ks, + 32*ROWB*blk
+    const int vbase = lds_off<D>(4 * hh + (i16 >> 2), 2 * g1 + ((i16 >> 1) & 1)) + 8 * (i16 & 1);  // ^ (64 db + 32 j2)
 
     int n_block, kv_head, batch;
     if (!decode_block(p, n_block, kv_head, batch, p.h_k)) return;
@@ -228,42 +274,42 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_kernel(const BParams p) {
     const int num_m = m_max - m_min;
     const int total_it = num_m * p.h_ratio;
 
-    const int key_w0 = n0 + wave * 32;
-    const int my_key = key_w0 + r;
+    const int key_w0 = n0 + wave * WKEYS;
 
-    // ---- K, V fragments of this wave's 32 keys: B operands of S = Q K^T and dP = dO V^T ---------------------
+    // ---- K, V fragments of this wave's keys: B operands of S = Q K^T and dP = dO V^T ---------------------------
     const T *kp = (const T *)p.k + sq_.k_base + (int64_t)kv_head * p.k_head_stride;
     const T *vp = (const T *)p.v + sq_.v_base + (int64_t)kv_head * p.v_head_stride;
-    u32x4 kf[KSTEPS], vf[KSTEPS];
+    // (the dK/dV accumulators live in AGPRs -- asm MFMAs with "+a" --, K/V stay in arch VGPRs: hipcc copies AGPR-pinned
+    //  B operands back and forth around every use here)
+    u32x4 kf[NB][KSTEPS], vf[NB][KSTEPS];
 #pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) {
-        const int d0 = ks * 16 + hh * 8;
-        u32x4 a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
-        if (my_key < sk && d0 < p.d) {
-            a = *(const u32x4 *)(kp + (int64_t)my_key * p.k_row_stride + d0);
-            b = *(const u32x4 *)(vp + (int64_t)my_key * p.v_row_stride + d0);
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const int key = key_w0 + 32 * nb + r;
+            const int d0 = ks * 16 + hh * 8;
+            u32x4 a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
+            if (key < sk && d0 < p.d) {
+                a = *(const u32x4 *)(kp + (int64_t)key * p.k_row_stride + d0);
+                b = *(const u32x4 *)(vp + (int64_t)key * p.v_row_stride + d0);
+            }
+            kf[nb][ks] = a;
+            vf[nb][ks] = b;
         }
-        kf[ks] = a;
-        vf[ks] = b;
-    }
 
-    f32x16 dk_acc[DBLOCKS], dv_acc[DBLOCKS];
+    f32x16 dk_acc[NB * DBLOCKS], dv_acc[NB * DBLOCKS];  // [nb * DBLOCKS + db]
+    {
+        const u32x4 z4 = {0, 0, 0, 0};
 #pragma unroll
-    for (int db = 0; db < DBLOCKS; ++db)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { dk_acc[db][i] = 0.f; dv_acc[db][i] = 0.f; }
+        for (int i = 0; i < NB * DBLOCKS; ++i) {
+            Mfma<T>::o_zero(dk_acc[i], z4);
+            Mfma<T>::o_zero(dv_acc[i], z4);
+        }
+    }
 
     // ---- Q / dO tile staging (register-staged, rows clamped into the sequence: clamped rows are masked) ---------
     u32x4 qreg[LD_PER_THREAD], greg[LD_PER_THREAD];
     float stat_reg = 0.f;
-    int ld_row[LD_PER_THREAD], ld_col[LD_PER_THREAD];
-#pragma unroll
-    for (int i = 0; i < LD_PER_THREAD; ++i) {
-        const int c = tid + i * NT;
-        ld_row[i] = c / CH_PER_ROW;
-        const int ch = c % CH_PER_ROW;
-        ld_col[i] = (ch * 8 < p.d) ? ch * 8 : 0;
-    }
     auto tile_head = [&](int it) { return kv_head * p.h_ratio + it / num_m; };
     auto tile_row0 = [&](int it) { return (m_min + it % num_m) * BM; };
     auto load_tile = [&](int it) {
@@ -272,9 +318,12 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_kernel(const BParams p) {
         const T *gp = (const T *)p.dout + sq_.do_base + (int64_t)head * p.do_head_stride;
 #pragma unroll
         for (int i = 0; i < LD_PER_THREAD; ++i) {
-            const int row = min(row0 + ld_row[i], sq - 1);
-            qreg[i] = *(const u32x4 *)(qp + (int64_t)row * p.q_row_stride + ld_col[i]);
-            greg[i] = *(const u32x4 *)(gp + (int64_t)row * p.do_row_stride + ld_col[i]);
+            const int c = tid + i * NT;
+            const int row = min(row0 + c / CH_PER_ROW, sq - 1);
+            const int ch = c % CH_PER_ROW;
+            const int col = (ch * 8 < p.d) ? ch * 8 : 0;
+            qreg[i] = *(const u32x4 *)(qp + (int64_t)row * p.q_row_stride + col);
+            greg[i] = *(const u32x4 *)(gp + (int64_t)row * p.do_row_stride + col);
         }
         if (tid < 2 * BM) {  // threads 0..63: LSE (log2 units), 64..127: D
             const int row = min(row0 + (tid & (BM - 1)), sq - 1);
@@ -318,52 +367,76 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_kernel(const BParams p) {
         // wave-level skip: no (row, key) pair of this tile x this wave's keys is visible
         bool skip = key_w0 >= sk;
         if (p.window_right >= 0) skip = skip || (key_w0 > row0 + BM - 1 + shift + p.window_right);
-        if (p.window_left >= 0) skip = skip || (key_w0 + 31 < row0 + shift - p.window_left);
+        if (p.window_left >= 0) skip = skip || (key_w0 + WKEYS - 1 < row0 + shift - p.window_left);
+        // masks are only evaluated where a boundary crosses this (64 rows x WKEYS keys) block; rows past the end of
+        // q are clamped copies: mask those too
+        bool need_mask = (key_w0 + WKEYS > sk) || (row0 + BM > sq);
+        if (p.window_right >= 0) need_mask = need_mask || (key_w0 + WKEYS - 1 > row0 + shift + p.window_right);
+        if (p.window_left >= 0) need_mask = need_mask || (key_w0 < row0 + BM - 1 + shift - p.window_left);
 
         if (!skip) {
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb) {
-                // ---- S = Q K^T and dP = dO V^T for 32 query rows x this wave's 32 keys -------------------
-                f32x16 s, dp;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+                // ---- S = Q K^T and dP = dO V^T for 32 query rows x this wave's keys -----------------------
+                f32x16 s[NB], dp[NB];
 #pragma unroll
                 for (int ks = 0; ks < KSTEPS; ++ks) {
-                    const int off = lds_off<D>(32 * rb + r, 2 * ks + hh);
+                    const int off = (kbase ^ (32 * ks)) + rb * (32 * ROWB);
                     const u32x4 qa = *(const u32x4 *)(qbuf + off);
                     const u32x4 ga = *(const u32x4 *)(gbuf + off);
-                    s = Elem<T>::mma(qa, kf[ks], s);
-                    dp = Elem<T>::mma(ga, vf[ks], dp);
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        if (ks == 0) { BMfma<T>::s_first_v(s[nb], qa, kf[nb][ks]); BMfma<T>::s_first_v(dp[nb], ga, vf[nb][ks]); }
+                        else { BMfma<T>::s_acc_v(s[nb], qa, kf[nb][ks]); BMfma<T>::s_acc_v(dp[nb], ga, vf[nb][ks]); }
+                    }
+                    if (ks & 1) __builtin_amdgcn_sched_barrier(0);  // keep hipcc from hoisting every LDS read to the top
                 }
+                drain_tiles<NB>(s, dp);
                 // ---- P and dS: key on the lane, query row = register ----------------------------------
+                auto pointwise = [&](auto mask_c) {
+                    constexpr bool MASK = decltype(mask_c)::value;
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const int rbase = 32 * rb + 8 * g4 + 4 * hh;
-                    const float4 l4 = *(const float4 *)(lse_s + cur * BM + rbase);
-                    const float4 d4 = *(const float4 *)(dsum_s + cur * BM + rbase);
-                    const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dsv[4] = {d4.x, d4.y, d4.z, d4.w};
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const int rbase = 32 * rb + 8 * g4 + 4 * hh;
+                        const float4 l4 = *(const float4 *)(lse_s + cur * BM + rbase);
+                        const float4 d4 = *(const float4 *)(dsum_s + cur * BM + rbase);
+                        const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dsv[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int i = 4 * g4 + e;
-                        const int qi = row0 + rbase + e;
-                        const int rel = qi + shift - my_key;
-                        bool vis = (my_key < sk) && (qi < sq);
-                        if (p.window_right >= 0) vis = vis && (rel + p.window_right >= 0);
-                        if (p.window_left >= 0) vis = vis && (rel <= p.window_left);
-                        float pv, ds;
-                        bwd_point<SOFTCAP>(p, s[i], dp[i], lv[e], dsv[e], alibi2, rel, vis, pv, ds);
-                        s[i] = pv;
-                        dp[i] = ds;
+                        for (int nb = 0; nb < NB; ++nb) {
+                            const int my_key = key_w0 + 32 * nb + r;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int i = 4 * g4 + e;
+                                const int qi = row0 + rbase + e;
+                                const int rel = qi + shift - my_key;
+                                bool vis = true;
+                                if constexpr (MASK) {
+                                    vis = (my_key < sk) && (qi < sq);
+                                    if (p.window_right >= 0) vis = vis && (rel + p.window_right >= 0);
+                                    if (p.window_left >= 0) vis = vis && (rel <= p.window_left);
+                                }
+                                float pv, ds;
+                                bwd_point<SOFTCAP, MASK>(p, s[nb][i], dp[nb][i], lv[e], dsv[e], alibi2, rel, vis, pv, ds);
+                                s[nb][i] = pv;
+                                dp[nb][i] = ds;
+                            }
+                        }
                     }
-                }
-                u32x4 pf[2], dsf[2];
+                };
+                __builtin_amdgcn_sched_barrier(0);
+                if (need_mask) pointwise(std::true_type{});
+                else pointwise(std::false_type{});
+                u32x4 pf[NB][2], dsf[NB][2];
 #pragma unroll
-                for (int st = 0; st < 2; ++st)
+                for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        pf[st][j] = Elem<T>::pack2(s[8 * st + 2 * j], s[8 * st + 2 * j + 1]);
-                        dsf[st][j] = Elem<T>::pack2(dp[8 * st + 2 * j], dp[8 * st + 2 * j + 1]);
-                    }
+                    for (int st = 0; st < 2; ++st)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            pf[nb][st][j] = Elem<T>::pack2(s[nb][8 * st + 2 * j], s[nb][8 * st + 2 * j + 1]);
+                            dsf[nb][st][j] = Elem<T>::pack2(dp[nb][8 * st + 2 * j], dp[nb][8 * st + 2 * j + 1]);
+                        }
+                __builtin_amdgcn_sched_barrier(0);
                 // ---- dV^T += dO^T P,  dK^T += Q^T dS  (A operands through transposing LDS reads) ----------
                 // element j of lane half hh of 16-row step st is query row 16st + 8(j>>2) + 4hh + (j&3)
 #pragma unroll
@@ -373,9 +446,7 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_kernel(const BParams p) {
                         u32x4 gt, qt;
 #pragma unroll
                         for (int j2 = 0; j2 < 2; ++j2) {
-                            const int row = 32 * rb + 16 * st + 8 * j2 + 4 * hh + (i16 >> 2);
-                            const int ch = db * 4 + 2 * g1 + ((i16 >> 1) & 1);
-                            const int off = lds_off<D>(row, ch) + 8 * (i16 & 1);
+                            const int off = (vbase ^ (64 * db + 32 * j2)) + (32 * rb + 16 * st + 8 * j2) * ROWB;
                             const u32x2 a = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                                 (__attribute__((address_space(3))) s16x4 *)(gbuf + off)));
                             const u32x2 b = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -383,8 +454,12 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_kernel(const BParams p) {
                             gt[2 * j2] = a[0]; gt[2 * j2 + 1] = a[1];
                             qt[2 * j2] = b[0]; qt[2 * j2 + 1] = b[1];
                         }
-                        dv_acc[db] = Elem<T>::mma(gt, pf[st], dv_acc[db]);
-                        dk_acc[db] = Elem<T>::mma(qt, dsf[st], dk_acc[db]);
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) {  // (s_nop 1 in front: VALU-packed P / dS -> MFMA operand)
+                            Mfma<T>::o_acc_pad(dv_acc[nb * DBLOCKS + db], gt, pf[nb][st]);
+                            Mfma<T>::o_acc_pad(dk_acc[nb * DBLOCKS + db], qt, dsf[nb][st]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
             }
@@ -395,35 +470,41 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_kernel(const BParams p) {
     }
 
     // ---- epilogue: dK^T / dV^T registers (lane = key, registers = head dim) -> LDS -> coalesced rows ------------
+    drain_acc(dk_acc);  // asm MFMA results -> VALU readers
+    drain_acc(dv_acc);
     T *dkp = (T *)p.dk + sq_.dk_base + (int64_t)kv_head * p.dk_head_stride;
     T *dvp = (T *)p.dv + sq_.dv_base + (int64_t)kv_head * p.dv_head_stride;
     char *obuf = smem + wave * (32 * O_ROW_BYTES);
 #pragma unroll
     for (int which = 0; which < 2; ++which) {
         const float f = which == 0 ? p.out_scale : 1.f;
-#pragma unroll
-        for (int db = 0; db < DBLOCKS; ++db)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const f32x16 &acc = which == 0 ? dk_acc[db] : dv_acc[db];
-                u32x2 w;
-                w[0] = Elem<T>::pack2(acc[4 * g4] * f, acc[4 * g4 + 1] * f);
-                w[1] = Elem<T>::pack2(acc[4 * g4 + 2] * f, acc[4 * g4 + 3] * f);
-                *(u32x2 *)(obuf + r * O_ROW_BYTES + (db * 32 + 8 * g4 + 4 * hh) * 2) = w;
-            }
-        __syncthreads();
         T *dst = which == 0 ? dkp : dvp;
         const int64_t rs = which == 0 ? p.dk_row_stride : p.dv_row_stride;
 #pragma unroll
-        for (int i = 0; i < (32 * CH_PER_ROW) / 64; ++i) {
-            const int c = lane + i * 64;
-            const int row = c / CH_PER_ROW, ch = c % CH_PER_ROW;
-            if (key_w0 + row < sk && ch * 8 < p.d) {
-                const u32x4 val = *(const u32x4 *)(obuf + row * O_ROW_BYTES + ch * 16);
-                *(u32x4 *)(dst + (int64_t)(key_w0 + row) * rs + ch * 8) = val;
+        for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+            for (int db = 0; db < DBLOCKS; ++db)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const f32x16 &acc = which == 0 ? dk_acc[nb * DBLOCKS + db] : dv_acc[nb * DBLOCKS + db];
+                    u32x2 w;
+                    w[0] = Elem<T>::pack2(acc[4 * g4] * f, acc[4 * g4 + 1] * f);
+                    w[1] = Elem<T>::pack2(acc[4 * g4 + 2] * f, acc[4 * g4 + 3] * f);
+                    *(u32x2 *)(obuf + r * O_ROW_BYTES + (db * 32 + 8 * g4 + 4 * hh) * 2) = w;
+                }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < (32 * CH_PER_ROW) / 64; ++i) {
+                const int c = lane + i * 64;
+                const int row = c / CH_PER_ROW, ch = c % CH_PER_ROW;
+                const int key = key_w0 + 32 * nb + row;
+                if (key < sk && ch * 8 < p.d) {
+                    const u32x4 val = *(const u32x4 *)(obuf + row * O_ROW_BYTES + ch * 16);
+                    *(u32x4 *)(dst + (int64_t)key * rs + ch * 8) = val;
+                }
             }
+            __syncthreads();
         }
-        __syncthreads();
     }
 }
 
@@ -435,12 +516,13 @@ constexpr int smem_bytes_dkdv() {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// dQ
+// dQ.  NB = 32-row query blocks per wave (K / V / K^T fragments from LDS feed NB MFMAs each).
 // ------------------------------------------------------------------------------------------------------------------
-template <typename T, int D, bool SOFTCAP>
+template <typename T, int D, int NB, bool SOFTCAP>
 __global__ __launch_bounds__(256, 1) void bwd_dq_kernel(const BParams p) {
     constexpr int NT = 256;
-    constexpr int BLOCK_M = 128;
+    constexpr int WROWS = 32 * NB;
+    constexpr int BLOCK_M = 4 * WROWS;
     constexpr int KSTEPS = D / 16;
     constexpr int DBLOCKS = D / 32;
     constexpr int CH_PER_ROW = D / 8;
@@ -458,6 +540,11 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_kernel(const BParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hh = lane >> 5;
     const int i16 = lane & 15, g1 = (lane >> 4) & 1;
+    // lane parts of the LDS read addresses; everything else is an immediate or one XOR (lds_off's swizzle only
+    // looks at the low 4 row bits, and chunk bits above the swizzle width pass through the XOR): see fa_fwd_kernel_w64.h
+    constexpr int ROWB = D * 2;
+    const int kbase = lds_off<D>(r, hh);                                                        // ^ 32*ks, + 32*ROWB*blk
+    const int vbase = lds_off<D>(4 * hh + (i16 >> 2), 2 * g1 + ((i16 >> 1) & 1)) + 8 * (i16 & 1);  // ^ (64 db + 32 j2)
 
     int m_block, head, batch;
     if (!decode_block(p, m_block, head, batch, p.h)) return;
@@ -474,8 +561,7 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_kernel(const BParams p) {
     const int n_min = key_lo / BLOCK_N;
     const int n_max = key_hi > 0 ? (key_hi + BLOCK_N - 1) / BLOCK_N : 0;
 
-    const int wrow = row_lo + wave * 32;
-    const int my_row = wrow + r;
+    const int wrow = row_lo + wave * WROWS;
     const bool wave_active = wrow < sq;
 
     const T *qp = (const T *)p.q + sq_.q_base + (int64_t)head * p.q_head_stride;
@@ -483,49 +569,53 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_kernel(const BParams p) {
     const T *kp = (const T *)p.k + sq_.k_base + (int64_t)kv_head * p.k_head_stride;
     const T *vp = (const T *)p.v + sq_.v_base + (int64_t)kv_head * p.v_head_stride;
 
-    // ---- Q, dO fragments (B operands), LSE and D of this lane's row -----------------------------------------
-    u32x4 qf[KSTEPS], gf[KSTEPS];
+    // ---- Q, dO fragments (B operands), LSE and D of this lane's rows ---------------------------------------
+    u32x4 qf[NB][KSTEPS], gf[NB][KSTEPS];
+    float lse2[NB], dsum[NB];
 #pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) {
-        const int d0 = ks * 16 + hh * 8;
-        u32x4 a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
-        if (my_row < sq && d0 < p.d) {
-            a = *(const u32x4 *)(qp + (int64_t)my_row * p.q_row_stride + d0);
-            b = *(const u32x4 *)(gp + (int64_t)my_row * p.do_row_stride + d0);
+    for (int nb = 0; nb < NB; ++nb) {
+        const int my_row = wrow + 32 * nb + r;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const int d0 = ks * 16 + hh * 8;
+            u32x4 a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
+            if (my_row < sq && d0 < p.d) {
+                a = *(const u32x4 *)(qp + (int64_t)my_row * p.q_row_stride + d0);
+                b = *(const u32x4 *)(gp + (int64_t)my_row * p.do_row_stride + d0);
+            }
+            qf[nb][ks] = a;
+            gf[nb][ks] = b;
+            asm volatile("; pin Q" : "+a"(qf[nb][ks]));   // B operands of every score MFMA: AGPR residents
+            asm volatile("; pin dO" : "+a"(gf[nb][ks]));
         }
-        qf[ks] = a;
-        gf[ks] = b;
-    }
-    float lse2 = INFINITY, dsum = 0.f;
-    if (my_row < sq) {
-        lse2 = p.lse[sq_.stat_base + (int64_t)head * sq_.lse_hs + my_row] * LOG2E;
-        dsum = p.dsum[sq_.dsum_base + (int64_t)head * sq_.dsum_hs + my_row];
+        lse2[nb] = INFINITY;  // rows past the end of q: P = exp2(-inf) = 0
+        dsum[nb] = 0.f;
+        if (my_row < sq) {
+            lse2[nb] = p.lse[sq_.stat_base + (int64_t)head * sq_.lse_hs + my_row] * LOG2E;
+            dsum[nb] = p.dsum[sq_.dsum_base + (int64_t)head * sq_.dsum_hs + my_row];
+        }
     }
     const float alibi2 = p.alibi ? p.alibi[(int64_t)batch * p.alibi_bs + head] * LOG2E : 0.f;
 
-    f32x16 dq_acc[DBLOCKS];
+    f32x16 dq_acc[NB * DBLOCKS];  // [nb * DBLOCKS + db], AGPRs
+    {
+        const u32x4 z4 = {0, 0, 0, 0};
 #pragma unroll
-    for (int db = 0; db < DBLOCKS; ++db)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) dq_acc[db][i] = 0.f;
+        for (int i = 0; i < NB * DBLOCKS; ++i) Mfma<T>::o_zero(dq_acc[i], z4);
+    }
 
     // ---- K/V staging (as the forward: clamped rows, register staged) -------------------------------------------
     u32x4 kreg[LD_PER_THREAD], vreg[LD_PER_THREAD];
-    int ld_row[LD_PER_THREAD], ld_col[LD_PER_THREAD];
-#pragma unroll
-    for (int i = 0; i < LD_PER_THREAD; ++i) {
-        const int c = tid + i * NT;
-        ld_row[i] = c / CH_PER_ROW;
-        const int ch = c % CH_PER_ROW;
-        ld_col[i] = (ch * 8 < p.d) ? ch * 8 : 0;
-    }
     auto load_tile = [&](int n) {
         const int k0 = n * BLOCK_N;
 #pragma unroll
         for (int i = 0; i < LD_PER_THREAD; ++i) {
-            const int row = min(k0 + ld_row[i], sk - 1);
-            kreg[i] = *(const u32x4 *)(kp + (int64_t)row * p.k_row_stride + ld_col[i]);
-            vreg[i] = *(const u32x4 *)(vp + (int64_t)row * p.v_row_stride + ld_col[i]);
+            const int c = tid + i * NT;
+            const int row = min(k0 + c / CH_PER_ROW, sk - 1);
+            const int ch = c % CH_PER_ROW;
+            const int col = (ch * 8 < p.d) ? ch * 8 : 0;
+            kreg[i] = *(const u32x4 *)(kp + (int64_t)row * p.k_row_stride + col);
+            vreg[i] = *(const u32x4 *)(vp + (int64_t)row * p.v_row_stride + col);
         }
     };
     auto store_tile = [&](int buf) {
@@ -552,65 +642,84 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_kernel(const BParams p) {
 
         const int k0 = n * BLOCK_N;
         bool skip = !wave_active;
-        if (p.window_right >= 0) skip = skip || (k0 > wrow + 31 + shift + p.window_right);
+        if (p.window_right >= 0) skip = skip || (k0 > wrow + WROWS - 1 + shift + p.window_right);
         if (p.window_left >= 0) skip = skip || (k0 + BLOCK_N - 1 < wrow + shift - p.window_left);
+        // masks only where a boundary crosses this (WROWS rows x 64 keys) block (rows past the end of q: LSE = +inf)
+        bool need_mask = (k0 + BLOCK_N > sk);
+        if (p.window_right >= 0) need_mask = need_mask || (k0 + BLOCK_N - 1 > wrow + shift + p.window_right);
+        if (p.window_left >= 0) need_mask = need_mask || (k0 < wrow + WROWS - 1 + shift - p.window_left);
 
         if (!skip) {
             const char *kbuf = smem + cur * TILE_BYTES;
             const char *vbuf = smem + (2 + cur) * TILE_BYTES;
-            // ---- S^T = K Q^T, dP^T = V dO^T: two 32-key blocks, query on the lane ------------------------
-            f32x16 s[2], dp[2];
+            // two 32-key halves, one after the other (keeps the live score accumulators at 32 NB registers)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { s[0][i] = 0.f; s[1][i] = 0.f; dp[0][i] = 0.f; dp[1][i] = 0.f; }
+            for (int kb = 0; kb < 2; ++kb) {
+                // ---- S^T = K Q^T, dP^T = V dO^T: 32 keys, query on the lane ----------------------------------
+                f32x16 s[NB], dp[NB];
 #pragma unroll
-            for (int ks = 0; ks < KSTEPS; ++ks) {
-                const int off = lds_off<D>(r, 2 * ks + hh);
-                const u32x4 ka0 = *(const u32x4 *)(kbuf + off);
-                const u32x4 ka1 = *(const u32x4 *)(kbuf + off + 32 * D * 2);
-                const u32x4 va0 = *(const u32x4 *)(vbuf + off);
-                const u32x4 va1 = *(const u32x4 *)(vbuf + off + 32 * D * 2);
-                s[0] = Elem<T>::mma(ka0, qf[ks], s[0]);
-                s[1] = Elem<T>::mma(ka1, qf[ks], s[1]);
-                dp[0] = Elem<T>::mma(va0, gf[ks], dp[0]);
-                dp[1] = Elem<T>::mma(va1, gf[ks], dp[1]);
-            }
+                for (int ks = 0; ks < KSTEPS; ++ks) {
+                    const int off = (kbase ^ (32 * ks)) + kb * (32 * ROWB);
+                    const u32x4 ka = *(const u32x4 *)(kbuf + off);
+                    const u32x4 va = *(const u32x4 *)(vbuf + off);
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int key = k0 + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-                    const int rel = my_row + shift - key;
-                    bool vis = (key < sk) && (my_row < sq);
-                    if (p.window_right >= 0) vis = vis && (rel + p.window_right >= 0);
-                    if (p.window_left >= 0) vis = vis && (rel <= p.window_left);
-                    float pv, ds;
-                    bwd_point<SOFTCAP>(p, s[kb][i], dp[kb][i], lse2, dsum, alibi2, rel, vis, pv, ds);
-                    dp[kb][i] = ds;
-                }
-            u32x4 dsf[4];
-#pragma unroll
-            for (int st = 0; st < 4; ++st) {
-                const int kb = st >> 1, b8 = (st & 1) * 8;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) dsf[st][j] = Elem<T>::pack2(dp[kb][b8 + 2 * j], dp[kb][b8 + 2 * j + 1]);
-            }
-            // ---- dQ^T += K^T dS^T ------------------------------------------------------------------------
-#pragma unroll
-            for (int db = 0; db < DBLOCKS; ++db) {
-#pragma unroll
-                for (int st = 0; st < 4; ++st) {
-                    u32x4 kt;
-#pragma unroll
-                    for (int j2 = 0; j2 < 2; ++j2) {
-                        const int row = 16 * st + 8 * j2 + 4 * hh + (i16 >> 2);
-                        const int ch = db * 4 + 2 * g1 + ((i16 >> 1) & 1);
-                        const int off = lds_off<D>(row, ch) + 8 * (i16 & 1);
-                        const u32x2 a = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                            (__attribute__((address_space(3))) s16x4 *)(kbuf + off)));
-                        kt[2 * j2] = a[0];
-                        kt[2 * j2 + 1] = a[1];
+                    for (int nb = 0; nb < NB; ++nb) {
+                        if (ks == 0) { Mfma<T>::s_first(s[nb], ka, qf[nb][ks]); Mfma<T>::s_first(dp[nb], va, gf[nb][ks]); }
+                        else { Mfma<T>::s_acc(s[nb], ka, qf[nb][ks]); Mfma<T>::s_acc(dp[nb], va, gf[nb][ks]); }
                     }
-                    dq_acc[db] = Elem<T>::mma(kt, dsf[st], dq_acc[db]);
+                    if (ks & 1) __builtin_amdgcn_sched_barrier(0);
+                }
+                drain_tiles<NB>(s, dp);
+                auto pointwise = [&](auto mask_c) {
+                    constexpr bool MASK = decltype(mask_c)::value;
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        const int my_row = wrow + 32 * nb + r;
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const int key = k0 + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                            const int rel = my_row + shift - key;
+                            bool vis = true;
+                            if constexpr (MASK) {
+                                vis = key < sk;
+                                if (p.window_right >= 0) vis = vis && (rel + p.window_right >= 0);
+                                if (p.window_left >= 0) vis = vis && (rel <= p.window_left);
+                            }
+                            float pv, ds;
+                            bwd_point<SOFTCAP, MASK>(p, s[nb][i], dp[nb][i], lse2[nb], dsum[nb], alibi2, rel, vis, pv, ds);
+                            dp[nb][i] = ds;
+                        }
+                    }
+                };
+                if (need_mask) pointwise(std::true_type{});
+                else pointwise(std::false_type{});
+                u32x4 dsf[NB][2];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int st = 0; st < 2; ++st)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            dsf[nb][st][j] = Elem<T>::pack2(dp[nb][8 * st + 2 * j], dp[nb][8 * st + 2 * j + 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- dQ^T += K^T dS^T ------------------------------------------------------------------------
+#pragma unroll
+                for (int db = 0; db < DBLOCKS; ++db) {
+#pragma unroll
+                    for (int st = 0; st < 2; ++st) {
+                        u32x4 kt;
+#pragma unroll
+                        for (int j2 = 0; j2 < 2; ++j2) {
+                            const int off = (vbase ^ (64 * db + 32 * j2)) + (32 * kb + 16 * st + 8 * j2) * ROWB;
+                            const u32x2 a = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                (__attribute__((address_space(3))) s16x4 *)(kbuf + off)));
+                            kt[2 * j2] = a[0];
+                            kt[2 * j2 + 1] = a[1];
+                        }
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) Mfma<T>::o_acc_pad(dq_acc[nb * DBLOCKS + db], kt, dsf[nb][st]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
             }
         }
@@ -620,31 +729,33 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_kernel(const BParams p) {
     }
 
     // ---- epilogue ---------------------------------------------------------------------------------------------
+    drain_acc(dq_acc);  // asm MFMA results -> VALU readers
     T *dqp = (T *)p.dq + sq_.dq_base + (int64_t)head * p.dq_head_stride;
-    if (wave_active) {
-        char *obuf = smem + wave * (32 * O_ROW_BYTES);
+    char *obuf = smem + wave * (32 * O_ROW_BYTES);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
         for (int db = 0; db < DBLOCKS; ++db)
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x16 &acc = dq_acc[nb * DBLOCKS + db];
                 u32x2 w;
-                w[0] = Elem<T>::pack2(dq_acc[db][4 * g4] * p.out_scale, dq_acc[db][4 * g4 + 1] * p.out_scale);
-                w[1] = Elem<T>::pack2(dq_acc[db][4 * g4 + 2] * p.out_scale, dq_acc[db][4 * g4 + 3] * p.out_scale);
+                w[0] = Elem<T>::pack2(acc[4 * g4] * p.out_scale, acc[4 * g4 + 1] * p.out_scale);
+                w[1] = Elem<T>::pack2(acc[4 * g4 + 2] * p.out_scale, acc[4 * g4 + 3] * p.out_scale);
                 *(u32x2 *)(obuf + r * O_ROW_BYTES + (db * 32 + 8 * g4 + 4 * hh) * 2) = w;
             }
-    }
-    __syncthreads();
-    if (wave_active) {
-        const char *obuf = smem + wave * (32 * O_ROW_BYTES);
+        __syncthreads();
 #pragma unroll
         for (int i = 0; i < (32 * CH_PER_ROW) / 64; ++i) {
             const int c = lane + i * 64;
             const int row = c / CH_PER_ROW, ch = c % CH_PER_ROW;
-            if (wrow + row < sq && ch * 8 < p.d) {
+            const int qrow = wrow + 32 * nb + row;
+            if (qrow < sq && ch * 8 < p.d) {
                 const u32x4 val = *(const u32x4 *)(obuf + row * O_ROW_BYTES + ch * 16);
-                *(u32x4 *)(dqp + (int64_t)(wrow + row) * p.dq_row_stride + ch * 8) = val;
+                *(u32x4 *)(dqp + (int64_t)qrow * p.dq_row_stride + ch * 8) = val;
             }
         }
+        __syncthreads();
     }
 }
 
