@@ -42,7 +42,9 @@ int64_t unit_grid(int64_t tiles, int blocks) {
 template <typename T, int D, bool SOFTCAP>
 int run_bwd(fa::BParams bp, int rows_q_max, int rows_k_max, hipStream_t stream) {
     // 32-wide blocks per wave (every LDS fragment feeds NB MFMAs): two wherever accumulators + resident operands fit
-    // the 512-register budget of a lone wave.  dQ: 2 for D <= 128; dK/dV (two accumulator sets + K and V): 2 for D = 64.
+    // the 512-register budget of a lone wave.  dQ: 2 for D <= 128; dK/dV (two accumulator sets + K and V): 2 for D = 64
+    // (at D = 128 two blocks would fill all 256 AGPRs with accumulators; hipcc then rotates the whole AGPR file
+    //  through v_accvgpr_mov to find temporaries -- measured 3x slower and not worth fighting).
     constexpr int NBQ = D <= 128 ? 2 : 1;
     constexpr int NBK = D <= 64 ? 2 : 1;
     // 1. D = rowsum(dO * O)
@@ -128,6 +130,9 @@ int fa_bwd_validate(const fa_bwd_params *p) {
         for (int64_t s : bs)
             if (s % 8 != 0) return FA_ERR_BAD_STRIDE;
     }
+    // tiles are addressed as 64-bit tile base + 32-bit (row * stride) lane offset
+    if (p->q_row_stride < 0 || p->do_row_stride < 0 || p->q_row_stride >= (1 << 24) || p->do_row_stride >= (1 << 24))
+        return FA_ERR_BAD_STRIDE;
     const void *ptrs[] = {p->q, p->k, p->v, p->o, p->dout, p->dq, p->dk, p->dv};
     for (const void *ptr : ptrs)
         if (reinterpret_cast<uintptr_t>(ptr) % 16 != 0) return FA_ERR_BAD_STRIDE;

@@ -307,23 +307,63 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_kernel(const BParams p) {
         }
     }
 
-    // ---- Q / dO tile staging (register-staged, rows clamped into the sequence: clamped rows are masked) ---------
-    u32x4 qreg[LD_PER_THREAD], greg[LD_PER_THREAD];
+    // ---- Q / dO tile staging: rows clamped into the sequence (clamped rows are masked).  LDS-DMA
+    //      (global_load_lds_dwordx4, no staging registers, swizzle applied on the source side: see
+    //      fa_fwd_kernel_w64.h) where a tile is <= 4 pieces per wave; register staged for D = 256. ------------------
+    constexpr bool DMA = LD_PER_THREAD <= 4;
+    constexpr int NSTAGE = DMA ? 1 : LD_PER_THREAD;
+    u32x4 qreg[NSTAGE], greg[NSTAGE];
     float stat_reg = 0.f;
     auto tile_head = [&](int it) { return kv_head * p.h_ratio + it / num_m; };
     auto tile_row0 = [&](int it) { return (m_min + it % num_m) * BM; };
-    auto load_tile = [&](int it) {
+    int dma_row[LD_PER_THREAD], dma_col[LD_PER_THREAD];
+    uint32_t q_off[LD_PER_THREAD], g_off[LD_PER_THREAD];  // byte offsets of this lane's chunks inside an in-range tile
+    const int q_rs = (int)p.q_row_stride, g_rs = (int)p.do_row_stride;  // host guarantees < 2^24
+    if constexpr (DMA) {
+#pragma unroll
+        for (int i = 0; i < LD_PER_THREAD; ++i) {
+            const int slot = wave * (LD_PER_THREAD * 64) + i * 64 + lane;  // 16-byte slot inside the tile image
+            const int row = slot / CH_PER_ROW;
+            int ch;  // inverse of lds_off<D>: the chunk stored at this slot
+            if constexpr (D == 64) ch = (slot % CH_PER_ROW) ^ ((((row >> 1) & 1) << 2) | ((row >> 2) & 3));
+            else ch = (slot % CH_PER_ROW) ^ (((row & 3) << 2) | ((row >> 2) & 3));
+            dma_row[i] = row;
+            dma_col[i] = (ch * 8 < p.d) ? ch * 8 : 0;
+            q_off[i] = (uint32_t)(row * q_rs + dma_col[i]) * 2u;
+            g_off[i] = (uint32_t)(row * g_rs + dma_col[i]) * 2u;
+        }
+    }
+    const uint32_t lds_wave = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem + wave * (LD_PER_THREAD * 1024);
+    auto load_tile = [&](int it, int buf) {
         const int head = tile_head(it), row0 = tile_row0(it);
         const T *qp = (const T *)p.q + sq_.q_base + (int64_t)head * p.q_head_stride;
         const T *gp = (const T *)p.dout + sq_.do_base + (int64_t)head * p.do_head_stride;
+        if constexpr (DMA) {
+            const T *qt = qp + (int64_t)row0 * p.q_row_stride, *gt = gp + (int64_t)row0 * p.do_row_stride;  // wave-uniform
+            if (row0 + BM <= sq) {
+                lds_dma<LD_PER_THREAD>(lds_wave + buf * TILE_BYTES, qt, q_off);
+                lds_dma<LD_PER_THREAD>(lds_wave + (2 + buf) * TILE_BYTES, gt, g_off);
+            } else {
+                uint32_t qo[LD_PER_THREAD], go[LD_PER_THREAD];
 #pragma unroll
-        for (int i = 0; i < LD_PER_THREAD; ++i) {
-            const int c = tid + i * NT;
-            const int row = min(row0 + c / CH_PER_ROW, sq - 1);
-            const int ch = c % CH_PER_ROW;
-            const int col = (ch * 8 < p.d) ? ch * 8 : 0;
-            qreg[i] = *(const u32x4 *)(qp + (int64_t)row * p.q_row_stride + col);
-            greg[i] = *(const u32x4 *)(gp + (int64_t)row * p.do_row_stride + col);
+                for (int i = 0; i < LD_PER_THREAD; ++i) {
+                    const int rel = min(row0 + dma_row[i], sq - 1) - row0;
+                    qo[i] = (uint32_t)(rel * q_rs + dma_col[i]) * 2u;
+                    go[i] = (uint32_t)(rel * g_rs + dma_col[i]) * 2u;
+                }
+                lds_dma<LD_PER_THREAD>(lds_wave + buf * TILE_BYTES, qt, qo);
+                lds_dma<LD_PER_THREAD>(lds_wave + (2 + buf) * TILE_BYTES, gt, go);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NSTAGE; ++i) {
+                const int c = tid + i * NT;
+                const int row = min(row0 + c / CH_PER_ROW, sq - 1);
+                const int ch = c % CH_PER_ROW;
+                const int col = (ch * 8 < p.d) ? ch * 8 : 0;
+                qreg[i] = *(const u32x4 *)(qp + (int64_t)row * p.q_row_stride + col);
+                greg[i] = *(const u32x4 *)(gp + (int64_t)row * p.do_row_stride + col);
+            }
         }
         if (tid < 2 * BM) {  // threads 0..63: LSE (log2 units), 64..127: D
             const int row = min(row0 + (tid & (BM - 1)), sq - 1);
@@ -336,28 +376,30 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_kernel(const BParams p) {
         }
     };
     auto store_tile = [&](int buf) {
+        if constexpr (!DMA) {
 #pragma unroll
-        for (int i = 0; i < LD_PER_THREAD; ++i) {
-            const int c = tid + i * NT;
-            const int off = lds_off<D>(c / CH_PER_ROW, c % CH_PER_ROW);
-            *(u32x4 *)(smem + buf * TILE_BYTES + off) = qreg[i];
-            *(u32x4 *)(smem + (2 + buf) * TILE_BYTES + off) = greg[i];
+            for (int i = 0; i < NSTAGE; ++i) {
+                const int c = tid + i * NT;
+                const int off = lds_off<D>(c / CH_PER_ROW, c % CH_PER_ROW);
+                *(u32x4 *)(smem + buf * TILE_BYTES + off) = qreg[i];
+                *(u32x4 *)(smem + (2 + buf) * TILE_BYTES + off) = greg[i];
+            }
         }
         if (tid < BM) lse_s[buf * BM + tid] = stat_reg;
         else if (tid < 2 * BM) dsum_s[buf * BM + tid - BM] = stat_reg;
     };
 
     if (total_it > 0) {
-        load_tile(0);
+        load_tile(0, 0);
         store_tile(0);
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see fa_fwd_kernel.h
-    __syncthreads();
+    tile_barrier<0>();                   // asm LDS-DMA pieces landed + workgroup barrier
 
     for (int it = 0; it < total_it; ++it) {
         const int cur = it & 1;
         const bool has_next = it + 1 < total_it;
-        if (has_next) load_tile(it + 1);
+        if (has_next) load_tile(it + 1, cur ^ 1);  // (buffer cur^1 was last read before the previous barrier)
 
         const int head = tile_head(it), row0 = tile_row0(it);
         const float alibi2 = p.alibi ? p.alibi[(int64_t)batch * p.alibi_bs + head] * LOG2E : 0.f;
@@ -466,7 +508,7 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_kernel(const BParams p) {
         }
 
         if (has_next) store_tile(cur ^ 1);
-        __syncthreads();
+        tile_barrier<0>();  // next tile's LDS-DMA landed (vmcnt(0)), LDS writes visible, workgroup barrier
     }
 
     // ---- epilogue: dK^T / dV^T registers (lane = key, registers = head dim) -> LDS -> coalesced rows ------------

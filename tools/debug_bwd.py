@@ -30,3 +30,8 @@ run(1, 128, 128, 1, 1, 64)
 run(1, 128, 256, 1, 1, 128)
 run(1, 200, 300, 2, 1, 64, causal=True)
 run(2, 64, 96, 4, 2, 32)
+run(1, 70, 90, 2, 2, 128, causal=True, dtype=torch.float16)
+run(1, 64, 64, 1, 1, 128)
+run(1, 64, 300, 1, 1, 128)
+run(1, 300, 64, 1, 1, 128)
+run(2, 1023, 1024, 4, 2, 128, causal=True)
