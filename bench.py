@@ -224,7 +224,8 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "attn fwd TFLOPS (aggregate over GPUs; per-GPU in per_gpu) + %MFMA-peak, bf16 hdim128 seq8192",
+            "metric": ("attn bwd TFLOPS (reference convention: 2.5 x forward FLOPs)" if args.workload.endswith("_bwd") else
+                       "attn fwd TFLOPS (aggregate over GPUs; per-GPU in per_gpu) + %MFMA-peak, bf16 hdim128 seq8192"),
             "value": round(value, 2),
             "unit": "TFLOP/s",
             "per_gpu": round(value / world, 2),

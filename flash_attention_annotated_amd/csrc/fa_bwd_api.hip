@@ -131,7 +131,8 @@ int fa_bwd_validate(const fa_bwd_params *p) {
             if (s % 8 != 0) return FA_ERR_BAD_STRIDE;
     }
     // tiles are addressed as 64-bit tile base + 32-bit (row * stride) lane offset
-    if (p->q_row_stride < 0 || p->do_row_stride < 0 || p->q_row_stride >= (1 << 24) || p->do_row_stride >= (1 << 24))
+    if (p->q_row_stride < 0 || p->do_row_stride < 0 || p->q_row_stride >= (1 << 24) || p->do_row_stride >= (1 << 24) ||
+        p->k_row_stride < 0 || p->v_row_stride < 0 || p->k_row_stride >= (1 << 24) || p->v_row_stride >= (1 << 24))
         return FA_ERR_BAD_STRIDE;
     const void *ptrs[] = {p->q, p->k, p->v, p->o, p->dout, p->dq, p->dk, p->dv};
     for (const void *ptr : ptrs)

@@ -646,41 +646,81 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_kernel(const BParams p) {
         for (int i = 0; i < NB * DBLOCKS; ++i) Mfma<T>::o_zero(dq_acc[i], z4);
     }
 
-    // ---- K/V staging (as the forward: clamped rows, register staged) -------------------------------------------
-    u32x4 kreg[LD_PER_THREAD], vreg[LD_PER_THREAD];
-    auto load_tile = [&](int n) {
-        const int k0 = n * BLOCK_N;
+    // ---- K/V staging: clamped rows; LDS-DMA where a tile is <= 4 pieces per wave, register staged for D = 256 ------
+    constexpr bool DMA = LD_PER_THREAD <= 4;
+    constexpr int NSTAGE = DMA ? 1 : LD_PER_THREAD;
+    u32x4 kreg[NSTAGE], vreg[NSTAGE];
+    int dma_row[LD_PER_THREAD], dma_col[LD_PER_THREAD];
+    uint32_t k_off[LD_PER_THREAD], v_off[LD_PER_THREAD];
+    const int k_rs = (int)p.k_row_stride, v_rs = (int)p.v_row_stride;  // host guarantees < 2^24
+    if constexpr (DMA) {
 #pragma unroll
         for (int i = 0; i < LD_PER_THREAD; ++i) {
-            const int c = tid + i * NT;
-            const int row = min(k0 + c / CH_PER_ROW, sk - 1);
-            const int ch = c % CH_PER_ROW;
-            const int col = (ch * 8 < p.d) ? ch * 8 : 0;
-            kreg[i] = *(const u32x4 *)(kp + (int64_t)row * p.k_row_stride + col);
-            vreg[i] = *(const u32x4 *)(vp + (int64_t)row * p.v_row_stride + col);
+            const int slot = wave * (LD_PER_THREAD * 64) + i * 64 + lane;
+            const int row = slot / CH_PER_ROW;
+            int ch;
+            if constexpr (D == 64) ch = (slot % CH_PER_ROW) ^ ((((row >> 1) & 1) << 2) | ((row >> 2) & 3));
+            else ch = (slot % CH_PER_ROW) ^ (((row & 3) << 2) | ((row >> 2) & 3));
+            dma_row[i] = row;
+            dma_col[i] = (ch * 8 < p.d) ? ch * 8 : 0;
+            k_off[i] = (uint32_t)(row * k_rs + dma_col[i]) * 2u;
+            v_off[i] = (uint32_t)(row * v_rs + dma_col[i]) * 2u;
+        }
+    }
+    const uint32_t lds_wave = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem + wave * (LD_PER_THREAD * 1024);
+    auto load_tile = [&](int n, int buf) {
+        const int k0 = n * BLOCK_N;
+        if constexpr (DMA) {
+            const T *kt = kp + (int64_t)k0 * p.k_row_stride, *vt = vp + (int64_t)k0 * p.v_row_stride;  // wave-uniform
+            if (k0 + BLOCK_N <= sk) {
+                lds_dma<LD_PER_THREAD>(lds_wave + buf * TILE_BYTES, kt, k_off);
+                lds_dma<LD_PER_THREAD>(lds_wave + (2 + buf) * TILE_BYTES, vt, v_off);
+            } else {
+                uint32_t ko[LD_PER_THREAD], vo[LD_PER_THREAD];
+#pragma unroll
+                for (int i = 0; i < LD_PER_THREAD; ++i) {
+                    const int rel = min(k0 + dma_row[i], sk - 1) - k0;
+                    ko[i] = (uint32_t)(rel * k_rs + dma_col[i]) * 2u;
+                    vo[i] = (uint32_t)(rel * v_rs + dma_col[i]) * 2u;
+                }
+                lds_dma<LD_PER_THREAD>(lds_wave + buf * TILE_BYTES, kt, ko);
+                lds_dma<LD_PER_THREAD>(lds_wave + (2 + buf) * TILE_BYTES, vt, vo);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NSTAGE; ++i) {
+                const int c = tid + i * NT;
+                const int row = min(k0 + c / CH_PER_ROW, sk - 1);
+                const int ch = c % CH_PER_ROW;
+                const int col = (ch * 8 < p.d) ? ch * 8 : 0;
+                kreg[i] = *(const u32x4 *)(kp + (int64_t)row * p.k_row_stride + col);
+                vreg[i] = *(const u32x4 *)(vp + (int64_t)row * p.v_row_stride + col);
+            }
         }
     };
     auto store_tile = [&](int buf) {
+        if constexpr (!DMA) {
 #pragma unroll
-        for (int i = 0; i < LD_PER_THREAD; ++i) {
-            const int c = tid + i * NT;
-            const int off = lds_off<D>(c / CH_PER_ROW, c % CH_PER_ROW);
-            *(u32x4 *)(smem + buf * TILE_BYTES + off) = kreg[i];
-            *(u32x4 *)(smem + (2 + buf) * TILE_BYTES + off) = vreg[i];
+            for (int i = 0; i < NSTAGE; ++i) {
+                const int c = tid + i * NT;
+                const int off = lds_off<D>(c / CH_PER_ROW, c % CH_PER_ROW);
+                *(u32x4 *)(smem + buf * TILE_BYTES + off) = kreg[i];
+                *(u32x4 *)(smem + (2 + buf) * TILE_BYTES + off) = vreg[i];
+            }
         }
     };
 
     if (n_min < n_max) {
-        load_tile(n_min);
+        load_tile(n_min, 0);
         store_tile(0);
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);
-    __syncthreads();
+    tile_barrier<0>();
 
     for (int n = n_min; n < n_max; ++n) {
         const int cur = (n - n_min) & 1;
         const bool has_next = n + 1 < n_max;
-        if (has_next) load_tile(n + 1);
+        if (has_next) load_tile(n + 1, cur ^ 1);
 
         const int k0 = n * BLOCK_N;
         bool skip = !wave_active;
@@ -767,7 +807,7 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_kernel(const BParams p) {
         }
 
         if (has_next) store_tile(cur ^ 1);
-        __syncthreads();
+        tile_barrier<0>();
     }
 
     // ---- epilogue ---------------------------------------------------------------------------------------------
