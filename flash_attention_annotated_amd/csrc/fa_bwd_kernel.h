@@ -297,14 +297,22 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_kernel(const BParams p) {
             vf[nb][ks] = b;
         }
 
+    // Accumulators pinned in AGPRs by asm MFMAs -- unless they would take ALL 256 AGPRs (D = 256): hipcc then has no
+    // AGPR temporaries left and rotates the whole file around the asm statements; that case stays compiler-managed.
+    constexpr bool PIN_ACC = 2 * NB * DBLOCKS * 16 < 256;
     f32x16 dk_acc[NB * DBLOCKS], dv_acc[NB * DBLOCKS];  // [nb * DBLOCKS + db]
-    {
+    if constexpr (PIN_ACC) {
         const u32x4 z4 = {0, 0, 0, 0};
 #pragma unroll
         for (int i = 0; i < NB * DBLOCKS; ++i) {
             Mfma<T>::o_zero(dk_acc[i], z4);
             Mfma<T>::o_zero(dv_acc[i], z4);
         }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NB * DBLOCKS; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { dk_acc[i][e] = 0.f; dv_acc[i][e] = 0.f; }
     }
 
     // ---- Q / dO tile staging: rows clamped into the sequence (clamped rows are masked).  LDS-DMA
@@ -421,17 +429,28 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_kernel(const BParams p) {
             for (int rb = 0; rb < 2; ++rb) {
                 // ---- S = Q K^T and dP = dO V^T for 32 query rows x this wave's keys -----------------------
                 f32x16 s[NB], dp[NB];
+                // LDS fragments are fetched PF steps ahead of the MFMAs that consume them (the wave is alone on its
+                // SIMD: nothing else hides the ~200-cycle LDS latency); sched_barrier pins the order
+                constexpr int PF = 2;
+                auto row_frag = [&](const char *buf, int ks) {
+                    return *(const u32x4 *)(buf + ((kbase ^ (32 * ks)) + rb * (32 * ROWB)));
+                };
+                u32x4 qa_r[PF + 1], ga_r[PF + 1];
+#pragma unroll
+                for (int i = 0; i < PF; ++i) { qa_r[i] = row_frag(qbuf, i); ga_r[i] = row_frag(gbuf, i); }
 #pragma unroll
                 for (int ks = 0; ks < KSTEPS; ++ks) {
-                    const int off = (kbase ^ (32 * ks)) + rb * (32 * ROWB);
-                    const u32x4 qa = *(const u32x4 *)(qbuf + off);
-                    const u32x4 ga = *(const u32x4 *)(gbuf + off);
+                    if (ks + PF < KSTEPS) {
+                        qa_r[(ks + PF) % (PF + 1)] = row_frag(qbuf, ks + PF);
+                        ga_r[(ks + PF) % (PF + 1)] = row_frag(gbuf, ks + PF);
+                    }
+                    const u32x4 qa = qa_r[ks % (PF + 1)], ga = ga_r[ks % (PF + 1)];
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) {
                         if (ks == 0) { BMfma<T>::s_first_v(s[nb], qa, kf[nb][ks]); BMfma<T>::s_first_v(dp[nb], ga, vf[nb][ks]); }
                         else { BMfma<T>::s_acc_v(s[nb], qa, kf[nb][ks]); BMfma<T>::s_acc_v(dp[nb], ga, vf[nb][ks]); }
                     }
-                    if (ks & 1) __builtin_amdgcn_sched_barrier(0);  // keep hipcc from hoisting every LDS read to the top
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 drain_tiles<NB>(s, dp);
                 // ---- P and dS: key on the lane, query row = register ----------------------------------
@@ -481,28 +500,42 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_kernel(const BParams p) {
                 __builtin_amdgcn_sched_barrier(0);
                 // ---- dV^T += dO^T P,  dK^T += Q^T dS  (A operands through transposing LDS reads) ----------
                 // element j of lane half hh of 16-row step st is query row 16st + 8(j>>2) + 4hh + (j&3)
+                auto tr_frag = [&](const char *buf, int t) {  // step t = (db, st)
+                    const int db = t >> 1, st = t & 1;
+                    u32x4 f;
 #pragma unroll
-                for (int db = 0; db < DBLOCKS; ++db) {
+                    for (int j2 = 0; j2 < 2; ++j2) {
+                        const int off = (vbase ^ (64 * db + 32 * j2)) + (32 * rb + 16 * st + 8 * j2) * ROWB;
+                        const u32x2 a = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) s16x4 *)(buf + off)));
+                        f[2 * j2] = a[0];
+                        f[2 * j2 + 1] = a[1];
+                    }
+                    return f;
+                };
+                constexpr int NT2 = 2 * DBLOCKS;
+                u32x4 gt_r[PF + 1], qt_r[PF + 1];
 #pragma unroll
-                    for (int st = 0; st < 2; ++st) {
-                        u32x4 gt, qt;
+                for (int i = 0; i < PF; ++i) { gt_r[i] = tr_frag(gbuf, i); qt_r[i] = tr_frag(qbuf, i); }
 #pragma unroll
-                        for (int j2 = 0; j2 < 2; ++j2) {
-                            const int off = (vbase ^ (64 * db + 32 * j2)) + (32 * rb + 16 * st + 8 * j2) * ROWB;
-                            const u32x2 a = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                                (__attribute__((address_space(3))) s16x4 *)(gbuf + off)));
-                            const u32x2 b = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                                (__attribute__((address_space(3))) s16x4 *)(qbuf + off)));
-                            gt[2 * j2] = a[0]; gt[2 * j2 + 1] = a[1];
-                            qt[2 * j2] = b[0]; qt[2 * j2 + 1] = b[1];
-                        }
+                for (int t = 0; t < NT2; ++t) {
+                    if (t + PF < NT2) {
+                        gt_r[(t + PF) % (PF + 1)] = tr_frag(gbuf, t + PF);
+                        qt_r[(t + PF) % (PF + 1)] = tr_frag(qbuf, t + PF);
+                    }
+                    const u32x4 gt = gt_r[t % (PF + 1)], qt = qt_r[t % (PF + 1)];
+                    const int db = t >> 1, st = t & 1;
 #pragma unroll
-                        for (int nb = 0; nb < NB; ++nb) {  // (s_nop 1 in front: VALU-packed P / dS -> MFMA operand)
+                    for (int nb = 0; nb < NB; ++nb) {  // (s_nop 1 in front: VALU-packed P / dS -> MFMA operand)
+                        if constexpr (PIN_ACC) {
                             Mfma<T>::o_acc_pad(dv_acc[nb * DBLOCKS + db], gt, pf[nb][st]);
                             Mfma<T>::o_acc_pad(dk_acc[nb * DBLOCKS + db], qt, dsf[nb][st]);
+                        } else {
+                            dv_acc[nb * DBLOCKS + db] = Elem<T>::mma(gt, pf[nb][st], dv_acc[nb * DBLOCKS + db]);
+                            dk_acc[nb * DBLOCKS + db] = Elem<T>::mma(qt, dsf[nb][st], dk_acc[nb * DBLOCKS + db]);
                         }
-                        __builtin_amdgcn_sched_barrier(0);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
@@ -512,8 +545,10 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_kernel(const BParams p) {
     }
 
     // ---- epilogue: dK^T / dV^T registers (lane = key, registers = head dim) -> LDS -> coalesced rows ------------
-    drain_acc(dk_acc);  // asm MFMA results -> VALU readers
-    drain_acc(dv_acc);
+    if constexpr (PIN_ACC) {
+        drain_acc(dk_acc);  // asm MFMA results -> VALU readers
+        drain_acc(dv_acc);
+    }
     T *dkp = (T *)p.dk + sq_.dk_base + (int64_t)kv_head * p.dk_head_stride;
     T *dvp = (T *)p.dv + sq_.dv_base + (int64_t)kv_head * p.dv_head_stride;
     char *obuf = smem + wave * (32 * O_ROW_BYTES);
@@ -739,17 +774,26 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_kernel(const BParams p) {
             for (int kb = 0; kb < 2; ++kb) {
                 // ---- S^T = K Q^T, dP^T = V dO^T: 32 keys, query on the lane ----------------------------------
                 f32x16 s[NB], dp[NB];
+                constexpr int PF = 2;  // LDS fragments are fetched PF steps ahead of their MFMAs (see bwd_dkdv_kernel)
+                auto row_frag = [&](const char *buf, int ks) {
+                    return *(const u32x4 *)(buf + ((kbase ^ (32 * ks)) + kb * (32 * ROWB)));
+                };
+                u32x4 ka_r[PF + 1], va_r[PF + 1];
+#pragma unroll
+                for (int i = 0; i < PF; ++i) { ka_r[i] = row_frag(kbuf, i); va_r[i] = row_frag(vbuf, i); }
 #pragma unroll
                 for (int ks = 0; ks < KSTEPS; ++ks) {
-                    const int off = (kbase ^ (32 * ks)) + kb * (32 * ROWB);
-                    const u32x4 ka = *(const u32x4 *)(kbuf + off);
-                    const u32x4 va = *(const u32x4 *)(vbuf + off);
+                    if (ks + PF < KSTEPS) {
+                        ka_r[(ks + PF) % (PF + 1)] = row_frag(kbuf, ks + PF);
+                        va_r[(ks + PF) % (PF + 1)] = row_frag(vbuf, ks + PF);
+                    }
+                    const u32x4 ka = ka_r[ks % (PF + 1)], va = va_r[ks % (PF + 1)];
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) {
                         if (ks == 0) { Mfma<T>::s_first(s[nb], ka, qf[nb][ks]); Mfma<T>::s_first(dp[nb], va, gf[nb][ks]); }
                         else { Mfma<T>::s_acc(s[nb], ka, qf[nb][ks]); Mfma<T>::s_acc(dp[nb], va, gf[nb][ks]); }
                     }
-                    if (ks & 1) __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 drain_tiles<NB>(s, dp);
                 auto pointwise = [&](auto mask_c) {
@@ -785,23 +829,31 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_kernel(const BParams p) {
                             dsf[nb][st][j] = Elem<T>::pack2(dp[nb][8 * st + 2 * j], dp[nb][8 * st + 2 * j + 1]);
                 __builtin_amdgcn_sched_barrier(0);
                 // ---- dQ^T += K^T dS^T ------------------------------------------------------------------------
+                auto tr_frag = [&](int t) {  // step t = (db, st)
+                    const int db = t >> 1, st = t & 1;
+                    u32x4 f;
 #pragma unroll
-                for (int db = 0; db < DBLOCKS; ++db) {
-#pragma unroll
-                    for (int st = 0; st < 2; ++st) {
-                        u32x4 kt;
-#pragma unroll
-                        for (int j2 = 0; j2 < 2; ++j2) {
-                            const int off = (vbase ^ (64 * db + 32 * j2)) + (32 * kb + 16 * st + 8 * j2) * ROWB;
-                            const u32x2 a = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                                (__attribute__((address_space(3))) s16x4 *)(kbuf + off)));
-                            kt[2 * j2] = a[0];
-                            kt[2 * j2 + 1] = a[1];
-                        }
-#pragma unroll
-                        for (int nb = 0; nb < NB; ++nb) Mfma<T>::o_acc_pad(dq_acc[nb * DBLOCKS + db], kt, dsf[nb][st]);
-                        __builtin_amdgcn_sched_barrier(0);
+                    for (int j2 = 0; j2 < 2; ++j2) {
+                        const int off = (vbase ^ (64 * db + 32 * j2)) + (32 * kb + 16 * st + 8 * j2) * ROWB;
+                        const u32x2 a = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) s16x4 *)(kbuf + off)));
+                        f[2 * j2] = a[0];
+                        f[2 * j2 + 1] = a[1];
                     }
+                    return f;
+                };
+                constexpr int NT2 = 2 * DBLOCKS;
+                u32x4 kt_r[PF + 1];
+#pragma unroll
+                for (int i = 0; i < PF; ++i) kt_r[i] = tr_frag(i);
+#pragma unroll
+                for (int t = 0; t < NT2; ++t) {
+                    if (t + PF < NT2) kt_r[(t + PF) % (PF + 1)] = tr_frag(t + PF);
+                    const u32x4 kt = kt_r[t % (PF + 1)];
+                    const int db = t >> 1, st = t & 1;
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) Mfma<T>::o_acc_pad(dq_acc[nb * DBLOCKS + db], kt, dsf[nb][st]);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }

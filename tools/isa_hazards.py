@@ -32,8 +32,13 @@ def scan(path, required=REQUIRED):
     window = []  # (states_so_far_after, dst_regs, text, lineno) of recent VALU writes
     last_trans = None  # (dst_regs, text, lineno) when the previous instruction was a transcendental
     mfma_out = []      # (states since issue, dst regs, text, lineno) of recent MFMAs
+    in_asm = False     # inside an inline-asm block (;;#ASMSTART .. ;;#ASMEND)
     for lineno, raw in enumerate(open(path), 1):
         l = raw.strip()
+        if l.startswith(';;#ASMSTART'):
+            in_asm = True
+        elif l.startswith(';;#ASMEND'):
+            in_asm = False
         m = re.match(r'^(_Z\w+):', l)
         if m:
             kernel = m.group(1)
@@ -78,7 +83,8 @@ def scan(path, required=REQUIRED):
             for t in ops[1:]:
                 srcs |= regs(t)
             for dist, dst, text, ln in window:
-                if dist < required and (dst & srcs):
+                # (hipcc's hazard recognizer covers the MFMAs it emits itself; only asm ones are unprotected)
+                if in_asm and dist < required and (dst & srcs):
                     violations.append((kernel, ln, text, lineno, l, dist))
             states = 1
             new_w = []
