@@ -25,6 +25,17 @@ def maybe_contiguous(x):
     return x.contiguous() if x is not None and x.stride(-1) != 1 else x
 
 
+def _precheck(q, k, v):
+    """The first two checks of mha_fwd (csrc/flash_attn/flash_api.cpp:370-377), made before the dispatcher sees the
+    tensors: the custom ops only exist for the GPU backend, and its own 'could not run ... CPU backend' error would
+    hide the reference's messages."""
+    if q.dtype not in (torch.float16, torch.bfloat16):
+        raise RuntimeError("FlashAttention only support fp16 and bf16 data type")
+    for t, n in ((q, "q"), (k, "k"), (v, "v")):
+        if not t.is_cuda:
+            raise RuntimeError(f"{n} must be on CUDA")
+
+
 def _pad_head_dim(*tensors):
     d = tensors[0].shape[-1]
     if d % 8 == 0:
@@ -33,8 +44,21 @@ def _pad_head_dim(*tensors):
     return tuple(F.pad(t, [0, pad]) for t in tensors)
 
 
-def _flash_attn_forward(q, k, v, dropout_p, softmax_scale, causal, window_size_left, window_size_right,
-                        softcap, alibi_slopes, return_softmax
+def round_multiple(x, m):
+    return (x + m - 1) // m * m
+
+
+# torch.compile surface (reference :56-73, 76, 109, 139-142): the four host entry points are torch.library custom
+# ops with fake (shape-only) implementations.  Namespace `flash_attn_amd` so that the reference package, which
+# registers `flash_attn::*` itself, can live in the same process (INTEGRATION.md option A).
+_custom_op = torch.library.custom_op
+_register_fake = torch.library.register_fake
+
+
+@_custom_op("flash_attn_amd::_flash_attn_forward", mutates_args=(), device_types="cuda")
+def _flash_attn_forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, dropout_p: float, softmax_scale: float,
+                        causal: bool, window_size_left: int, window_size_right: int, softcap: float,
+                        alibi_slopes: Optional[torch.Tensor], return_softmax: bool
                         ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
     """reference :76-106"""
     q, k, v = [maybe_contiguous(x) for x in (q, k, v)]
@@ -44,9 +68,28 @@ def _flash_attn_forward(q, k, v, dropout_p, softmax_scale, causal, window_size_l
     return out, softmax_lse, S_dmask, rng_state
 
 
-def _flash_attn_backward(dout, q, k, v, out, softmax_lse, dq, dk, dv, dropout_p, softmax_scale, causal,
-                         window_size_left, window_size_right, softcap, alibi_slopes, deterministic,
-                         rng_state=None) -> torch.Tensor:
+@_register_fake("flash_attn_amd::_flash_attn_forward")
+def _flash_attn_forward_fake(q, k, v, dropout_p, softmax_scale, causal, window_size_left, window_size_right, softcap,
+                             alibi_slopes, return_softmax):
+    """reference :109-136 (on HIP the fake `p` is the unrounded (b, h, sq, sk), :130-131)"""
+    batch_size, seqlen_q, num_heads, _ = q.shape
+    seqlen_k = k.shape[1]
+    out = torch.empty_like(q, memory_format=torch.contiguous_format)
+    softmax_lse = torch.empty((batch_size, num_heads, seqlen_q), dtype=torch.float32, device=q.device)
+    p = torch.empty((0,), dtype=q.dtype, device=q.device)
+    if return_softmax:
+        p = torch.empty((batch_size, num_heads, seqlen_q, seqlen_k), dtype=q.dtype, device=q.device)
+    rng_state = torch.empty((2,), dtype=torch.int64, device=q.device)
+    return out, softmax_lse, p, rng_state
+
+
+@_custom_op("flash_attn_amd::_flash_attn_backward", mutates_args=("dq", "dk", "dv"), device_types="cuda")
+def _flash_attn_backward(dout: torch.Tensor, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor,
+                         softmax_lse: torch.Tensor, dq: Optional[torch.Tensor], dk: Optional[torch.Tensor],
+                         dv: Optional[torch.Tensor], dropout_p: float, softmax_scale: float, causal: bool,
+                         window_size_left: int, window_size_right: int, softcap: float,
+                         alibi_slopes: Optional[torch.Tensor], deterministic: bool,
+                         rng_state: Optional[torch.Tensor] = None) -> torch.Tensor:
     """reference :241-289"""
     dout, q, k, v, out = [maybe_contiguous(x) for x in (dout, q, k, v, out)]
     dq, dk, dv, softmax_d = flash_attn_gpu.bwd(
@@ -55,10 +98,23 @@ def _flash_attn_backward(dout, q, k, v, out, softmax_lse, dq, dk, dv, dropout_p,
     return softmax_d
 
 
-def _flash_attn_varlen_backward(dout, q, k, v, out, softmax_lse, dq, dk, dv, cu_seqlens_q, cu_seqlens_k,
-                                max_seqlen_q, max_seqlen_k, dropout_p, softmax_scale, causal, window_size_left,
-                                window_size_right, softcap, alibi_slopes, deterministic, rng_state=None,
-                                zero_tensors=False) -> torch.Tensor:
+@_register_fake("flash_attn_amd::_flash_attn_backward")
+def _flash_attn_backward_fake(dout, q, k, v, out, softmax_lse, dq, dk, dv, dropout_p, softmax_scale, causal,
+                              window_size_left, window_size_right, softcap, alibi_slopes, deterministic,
+                              rng_state=None):
+    """reference :292-325"""
+    batch_size, seqlen_q, num_heads, _ = q.shape
+    return torch.empty((batch_size, num_heads, round_multiple(seqlen_q, 128)), device=q.device, dtype=torch.float32)
+
+
+@_custom_op("flash_attn_amd::_flash_attn_varlen_backward", mutates_args=("dq", "dk", "dv"), device_types="cuda")
+def _flash_attn_varlen_backward(dout: torch.Tensor, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
+                                out: torch.Tensor, softmax_lse: torch.Tensor, dq: Optional[torch.Tensor],
+                                dk: Optional[torch.Tensor], dv: Optional[torch.Tensor], cu_seqlens_q: torch.Tensor,
+                                cu_seqlens_k: torch.Tensor, max_seqlen_q: int, max_seqlen_k: int, dropout_p: float,
+                                softmax_scale: float, causal: bool, window_size_left: int, window_size_right: int,
+                                softcap: float, alibi_slopes: Optional[torch.Tensor], deterministic: bool,
+                                rng_state: Optional[torch.Tensor] = None, zero_tensors: bool = False) -> torch.Tensor:
     """reference :337-392"""
     dout, q, k, v, out = [maybe_contiguous(x) for x in (dout, q, k, v, out)]
     dq, dk, dv, softmax_d = flash_attn_gpu.varlen_bwd(
@@ -68,10 +124,25 @@ def _flash_attn_varlen_backward(dout, q, k, v, out, softmax_lse, dq, dk, dv, cu_
     return softmax_d
 
 
-def _flash_attn_varlen_forward(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, dropout_p,
-                               softmax_scale, causal, window_size_left=-1, window_size_right=-1, softcap=0.0,
-                               alibi_slopes=None, return_softmax=False, block_table=None, leftpad_k=None,
-                               seqused_k=None, zero_tensors=False
+@_register_fake("flash_attn_amd::_flash_attn_varlen_backward")
+def _flash_attn_varlen_backward_fake(dout, q, k, v, out, softmax_lse, dq, dk, dv, cu_seqlens_q, cu_seqlens_k,
+                                     max_seqlen_q, max_seqlen_k, dropout_p, softmax_scale, causal, window_size_left,
+                                     window_size_right, softcap, alibi_slopes, deterministic, rng_state=None,
+                                     zero_tensors=False):
+    """reference :395-430"""
+    batch_size = cu_seqlens_q.numel() - 1
+    total_q, num_heads, _ = q.shape
+    return torch.empty((num_heads, total_q + 128 * batch_size), device=q.device, dtype=torch.float32)
+
+
+@_custom_op("flash_attn_amd::_flash_attn_varlen_forward", mutates_args=(), device_types="cuda")
+def _flash_attn_varlen_forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_seqlens_q: torch.Tensor,
+                               cu_seqlens_k: torch.Tensor, max_seqlen_q: int, max_seqlen_k: int, dropout_p: float,
+                               softmax_scale: float, causal: bool, window_size_left: int = -1,
+                               window_size_right: int = -1, softcap: float = 0.0,
+                               alibi_slopes: Optional[torch.Tensor] = None, return_softmax: bool = False,
+                               block_table: Optional[torch.Tensor] = None, leftpad_k: Optional[torch.Tensor] = None,
+                               seqused_k: Optional[torch.Tensor] = None, zero_tensors: bool = False
                                ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
     """reference :145-193"""
     q, k, v = [maybe_contiguous(x) for x in (q, k, v)]
@@ -82,10 +153,28 @@ def _flash_attn_varlen_forward(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q
     return out, softmax_lse, S_dmask, rng_state
 
 
+@_register_fake("flash_attn_amd::_flash_attn_varlen_forward")
+def _flash_attn_varlen_forward_fake(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, dropout_p,
+                                    softmax_scale, causal, window_size_left=-1, window_size_right=-1, softcap=0.0,
+                                    alibi_slopes=None, return_softmax=False, block_table=None, leftpad_k=None,
+                                    seqused_k=None, zero_tensors=False):
+    """reference :196-233"""
+    batch_size = cu_seqlens_q.numel() - 1
+    total_q, num_heads, _ = q.shape
+    out = torch.empty_like(q, memory_format=torch.contiguous_format)
+    softmax_lse = torch.empty((num_heads, total_q), dtype=torch.float32, device=q.device)
+    p = torch.empty((0,), dtype=q.dtype, device=q.device)
+    if return_softmax:
+        p = torch.empty((batch_size, num_heads, max_seqlen_q, max_seqlen_k), dtype=q.dtype, device=q.device)
+    rng_state = torch.empty((2,), dtype=torch.int64, device=q.device)
+    return out, softmax_lse, p, rng_state
+
+
 class FlashAttnFunc(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, dropout_p, softmax_scale, causal, window_size, softcap, alibi_slopes,
                 deterministic, return_softmax, is_grad_enabled):
+        _precheck(q, k, v)
         is_grad = is_grad_enabled and any(x.requires_grad for x in [q, k, v])
         if softmax_scale is None:
             softmax_scale = q.shape[-1] ** (-0.5)
@@ -125,6 +214,7 @@ class FlashAttnVarlenFunc(torch.autograd.Function):
     def forward(ctx, q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, dropout_p, softmax_scale,
                 causal, window_size, softcap, alibi_slopes, deterministic, return_softmax, block_table,
                 is_grad_enabled):
+        _precheck(q, k, v)
         is_grad = is_grad_enabled and any(x.requires_grad for x in [q, k, v])
         if softmax_scale is None:
             softmax_scale = q.shape[-1] ** (-0.5)

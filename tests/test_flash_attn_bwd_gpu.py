@@ -221,3 +221,40 @@ def test_bwd_errors_are_the_reference_messages():
         m.bwd(q, q, q, q, q, lse, None, None, None, None, 0.1, 0.125, False, -1, -1, 0.0, False, None, None)
     with pytest.raises(RuntimeError, match="dq must have shape"):
         m.bwd(q, q, q, q, q, lse, q[:, :4], None, None, None, 0.0, 0.125, False, -1, -1, 0.0, False, None, None)
+
+
+def test_torch_compile_traces_forward_and_backward():
+    """The custom-op + fake registration (reference flash_attn_interface.py:76,109,241,292) lets Dynamo/AOTAutograd trace
+    through the op; aot_eager runs the real kernels behind the traced graph."""
+    fa = _api()
+    torch.manual_seed(7)
+    q, k, v = (torch.randn(2, 160, 4, 64, dtype=torch.bfloat16, device=DEV, requires_grad=True) for _ in range(3))
+    g = torch.randn(2, 160, 4, 64, dtype=torch.bfloat16, device=DEV)
+
+    def f(q, k, v):
+        return fa.flash_attn_func(q, k, v, causal=True) * 2.0
+    out_e = f(q, k, v)
+    grads_e = torch.autograd.grad(out_e, (q, k, v), g)
+    fc = torch.compile(f, backend="aot_eager", fullgraph=True)
+    out_c = fc(q, k, v)
+    grads_c = torch.autograd.grad(out_c, (q, k, v), g)
+    assert torch.equal(out_e, out_c)
+    for a, b in zip(grads_e, grads_c):
+        assert torch.equal(a, b)
+
+
+def test_attention_modules_match_the_functions():
+    fa = _api()
+    from flash_attention_annotated_amd.modules.mha import FlashCrossAttention, FlashSelfAttention
+    torch.manual_seed(8)
+    qkv = torch.randn(2, 130, 3, 4, 64, dtype=torch.float16, device=DEV)
+    assert torch.equal(FlashSelfAttention(causal=True)(qkv), fa.flash_attn_qkvpacked_func(qkv, causal=True))
+    q = torch.randn(2, 70, 4, 64, dtype=torch.float16, device=DEV)
+    kv = torch.randn(2, 130, 2, 2, 64, dtype=torch.float16, device=DEV)
+    slopes = torch.rand(4, device=DEV) * 0.3
+    got = FlashCrossAttention(alibi_slopes=slopes, window_size=(50, 10))(q, kv)
+    assert torch.equal(got, fa.flash_attn_kvpacked_func(q, kv, alibi_slopes=slopes, window_size=(50, 10)))
+    cu = torch.tensor([0, 100, 130], dtype=torch.int32, device=DEV)
+    packed = qkv[0, :130].contiguous()
+    out = FlashSelfAttention()(packed, cu_seqlens=cu, max_seqlen=100)
+    assert torch.equal(out, fa.flash_attn_varlen_qkvpacked_func(packed, cu, 100))

@@ -72,3 +72,33 @@ def test_shard_range_partitions():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_torch_library_ops_have_fake_implementations():
+    """torch.compile surface (reference flash_attn/flash_attn_interface.py:76,109-136,241,292-325): the host entry
+    points are custom ops whose fake kernels give the shapes of the real ones; meta tensors exercise them."""
+    q = torch.empty(2, 100, 4, 64, dtype=torch.bfloat16, device="meta")
+    k = torch.empty(2, 130, 2, 64, dtype=torch.bfloat16, device="meta")
+    out, lse, p, rng = torch.ops.flash_attn_amd._flash_attn_forward(q, k, k, 0.0, 0.125, True, -1, -1, 0.0, None, False)
+    assert out.shape == q.shape and lse.shape == (2, 4, 100) and lse.dtype == torch.float32 and p.shape == (0,)
+    sd = torch.ops.flash_attn_amd._flash_attn_backward(out, q, k, k, out, lse, torch.empty_like(q), torch.empty_like(k),
+                                                       torch.empty_like(k), 0.0, 0.125, True, -1, -1, 0.0, None, False)
+    assert sd.shape == (2, 4, 128)
+    qv = torch.empty(393, 4, 64, dtype=torch.float16, device="meta")
+    cu = torch.empty(4, dtype=torch.int32, device="meta")
+    out, lse, _, _ = torch.ops.flash_attn_amd._flash_attn_varlen_forward(qv, qv, qv, cu, cu, 256, 256, 0.0, 0.125, False)
+    assert out.shape == qv.shape and lse.shape == (4, 393)
+    sd = torch.ops.flash_attn_amd._flash_attn_varlen_backward(out, qv, qv, qv, out, lse, None, None, None, cu, cu, 256,
+                                                              256, 0.0, 0.125, False, -1, -1, 0.0, None, False)
+    assert sd.shape == (4, 393 + 128 * 3)
+
+
+def test_attention_modules_mirror_the_reference_constructors():
+    from flash_attention_annotated_amd.modules.mha import FlashCrossAttention, FlashSelfAttention
+    sa = FlashSelfAttention(causal=True, softmax_scale=0.1, attention_dropout=0.0, window_size=(4, 0))
+    ca = FlashCrossAttention(causal=False, alibi_slopes=torch.rand(4))
+    assert [p for p in inspect.signature(sa.forward).parameters] == ["qkv", "causal", "cu_seqlens", "max_seqlen"]
+    assert [p for p in inspect.signature(ca.forward).parameters] == [
+        "q", "kv", "causal", "cu_seqlens", "max_seqlen", "cu_seqlens_k", "max_seqlen_k"]
+    with pytest.raises(AssertionError):
+        sa(torch.randn(1, 8, 3, 2, 64, dtype=torch.bfloat16))  # CPU tensor: rejected like the reference does
