@@ -37,6 +37,10 @@ WORKLOADS = {
     # (benchmarks/benchmark_flash_attention.py:27-30 mode="bwd")
     "c2_bwd": ("C2 backward b4 h16 d128 s8192 bf16 non-causal", 4, 16, 16, 8192, 128, False, None),
     "c3_bwd": ("C3 backward b4 h16 d128 s16384 bf16 causal", 4, 16, 16, 16384, 128, True, None),
+    # decode step over a KV cache: sq = 1, GQA 32/8, cache of 8192 rows per sequence, one new row
+    # appended in place; HBM-bound: the figure of merit is cache bytes read per second
+    "decode": ("decode b32 hq32 hkv8 d128 cache 8192 bf16 (flash_attn_with_kvcache, 1 new row appended)", 32, 32, 8,
+               8192, 128, False, None),
     "c5": ("C5 fp8 e4m3 b4 h16 d128 s8192 non-causal (fp8 storage, exact bf16 expansion pass + bf16 MFMA)", 4, 16, 16,
            8192, 128, False, None),
 }
@@ -169,8 +173,18 @@ def main():
         lib.fa_set_default_variant(args.variant)
 
     w = WORKLOADS[args.workload]
-    (q, k, v), extra = make_inputs(w, device, seed=rank)  # each rank: its own batch shard, already in HBM
+    if args.workload == "decode":
+        (q, k, v), extra = (None, None, None), {}
+    else:
+        (q, k, v), extra = make_inputs(w, device, seed=rank)  # each rank: its own batch shard, already in HBM
 
+    decode_state = None
+    if args.workload == "decode":
+        _, b_, h_, hk_, s_, d_, _, _ = w
+        g = torch.Generator(device=device).manual_seed(rank)
+        mk = lambda *shape: torch.randn(*shape, device=device, dtype=torch.bfloat16, generator=g)
+        decode_state = (mk(b_, 1, h_, d_), mk(b_, s_, hk_, d_), mk(b_, s_, hk_, d_), mk(b_, 1, hk_, d_), mk(b_, 1, hk_, d_),
+                        torch.full((b_,), s_ - 1, dtype=torch.int32, device=device))
     bwd_state = None
     if args.workload.endswith("_bwd"):
         from flash_attention_annotated_amd import flash_attn_2_cuda as ext
@@ -180,6 +194,9 @@ def main():
         bwd_state = (ext, g, out, lse, torch.empty_like(q), torch.empty_like(k), torch.empty_like(v), scale)
 
     def step():
+        if decode_state is not None:
+            qd, kc, vc, kn, vn, cs = decode_state
+            return fa.flash_attn_with_kvcache(qd, kc, vc, kn, vn, cache_seqlens=cs)
         if bwd_state is not None:
             ext, g, out, lse, dq, dk, dv, scale = bwd_state
             return ext.bwd(g, q, k, v, out, lse, dq, dk, dv, None, 0.0, scale, w[6], -1, -1, 0.0, False, None, None)
@@ -222,7 +239,25 @@ def main():
     value = total_flops / elapsed / 1e12
     achieved = flops / (avg_kernel_ms * 1e-3) / 1e12
 
-    if rank == 0:
+    if rank == 0 and args.workload == "decode":
+        _, b_, h_, hk_, s_, d_, _, _ = w
+        cache_bytes = 2 * b_ * s_ * hk_ * d_ * 2            # K and V rows read once
+        other = 2 * b_ * h_ * d_ * 2 + 4 * b_ * hk_ * d_ * 2  # q, out, appended rows (read + write)
+        gbs = (cache_bytes + other) * world * args.steps / elapsed / 1e9
+        ach = (cache_bytes + other) / (avg_kernel_ms * 1e-3) / 1e9
+        print(json.dumps({
+            "metric": "decode attention: KV-cache bytes streamed per second (aggregate over GPUs)", "value": round(gbs, 1),
+            "unit": "GB/s", "per_gpu": round(gbs / world, 1), "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic (torch.randn N(0,1), seed = rank)",
+            "config": {"workload": w[0], "batch_per_gpu": b_, "heads_q": h_, "heads_kv": hk_, "cache_len": s_,
+                       "head_dim": d_, "sharding": f"batch shard x{world}, no collective"},
+            "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s",
+                         "frac": round(ach / 8000.0, 4), "traffic": None, "step_ms_avg": round(avg_kernel_ms, 4),
+                         "step_ms_min": round(kernel_ms[0], 4), "algorithmic_bytes_per_step": cache_bytes + other,
+                         "note": "one step = append launch + attention launch (HIP events around both)"},
+            "cpu_baseline": None}), flush=True)
+    elif rank == 0:
         out = {
             "metric": ("attn bwd TFLOPS (reference convention: 2.5 x forward FLOPs)" if args.workload.endswith("_bwd") else
                        "attn fwd TFLOPS (aggregate over GPUs; per-GPU in per_gpu) + %MFMA-peak, bf16 hdim128 seq8192"),

@@ -26,7 +26,7 @@ def aligned(t):
 
 def launch(q, k, v, out, lse, *, varlen, batch, max_seqlen_q, max_seqlen_k, softmax_scale, causal, window_left,
            window_right, softcap, cu_seqlens_q=None, cu_seqlens_k=None, seqused_q=None, seqused_k=None,
-           q_descale=None, k_descale=None, v_descale=None, alibi_slopes=None):
+           q_descale=None, k_descale=None, v_descale=None, alibi_slopes=None, kv_batch_idx=None):
     """q/k/v/out: dense (b, s, h, d) or packed (total, h, d) tensors on one GPU, last stride 1, aligned()."""
     lib = _lib.load()
     prm = _lib.new_params()
@@ -62,6 +62,7 @@ def launch(q, k, v, out, lse, *, varlen, batch, max_seqlen_q, max_seqlen_k, soft
     if alibi_slopes is not None:  # (h) or (b, h) fp32, last stride 1 (checked by the callers)
         prm.alibi_slopes = ptr(alibi_slopes)
         prm.alibi_slopes_batch_stride = alibi_slopes.stride(0) if alibi_slopes.dim() == 2 else 0
+    prm.kv_batch_idx = ptr(kv_batch_idx)
     workspace = None
     need = lib.fa_fwd_workspace_size(ctypes.byref(prm))
     if need < 0:
@@ -121,3 +122,24 @@ def launch_bwd(dout, q, k, v, out, lse, dq, dk, dv, softmax_d, *, varlen, batch,
     st = lib.fa_bwd(ctypes.byref(prm), ctypes.c_void_p(stream))
     if st != 0:
         raise RuntimeError(f"fa_bwd failed ({st}): {_lib.strerror(st)}")
+
+
+def kvcache_append(k_new, v_new, k_cache, v_cache, cache_seqlens, cache_batch_idx=None):
+    """(b, s_new, h_k, d) rows appended in place to (b_cache, s_cache, h_k, d) caches at cache_seqlens (int32, (b,))."""
+    lib = _lib.load()
+    prm = _lib.FaKvcacheAppendParams()
+    prm.abi_version = _lib.FA_ABI_VERSION
+    prm.struct_size = ctypes.sizeof(_lib.FaKvcacheAppendParams)
+    prm.k_new, prm.v_new, prm.k_cache, prm.v_cache = ptr(k_new), ptr(v_new), ptr(k_cache), ptr(v_cache)
+    for name, t in (("knew", k_new), ("vnew", v_new), ("kcache", k_cache), ("vcache", v_cache)):
+        setattr(prm, f"{name}_batch_stride", t.stride(0))
+        setattr(prm, f"{name}_row_stride", t.stride(1))
+        setattr(prm, f"{name}_head_stride", t.stride(2))
+    prm.b, prm.seqlen_new, prm.h_k, prm.d = k_new.shape
+    prm.seqlen_cache = k_cache.shape[1]
+    prm.cache_seqlens = ptr(cache_seqlens)
+    prm.cache_batch_idx = ptr(cache_batch_idx)
+    stream = torch.cuda.current_stream(k_new.device).cuda_stream
+    st = lib.fa_kvcache_append(ctypes.byref(prm), ctypes.c_void_p(stream))
+    if st != 0:
+        raise RuntimeError(f"fa_kvcache_append failed ({st}): {_lib.strerror(st)}")

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, LIB_NAME)
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
-FA_ABI_VERSION = 3
+FA_ABI_VERSION = 4
 FA_DTYPE_FP16, FA_DTYPE_BF16, FA_DTYPE_FP8_E4M3 = 0, 1, 2
 
 # every symbol include/fa_fwd.h declares (tests check the .so exports all of them)
@@ -27,6 +27,8 @@ EXPORTED_SYMBOLS = (
     "fa_abi_version",
     "fa_fwd_tile_shape",
     "fa_set_default_variant",
+    "fa_kvcache_append",
+    "fa_kvcache_append_params_size",
     # include/fa_bwd.h
     "fa_bwd",
     "fa_bwd_validate",
@@ -89,7 +91,21 @@ class FaFwdParams(ctypes.Structure):
         ("workspace_bytes", ctypes.c_uint64),
         ("alibi_slopes", ctypes.c_void_p),
         ("alibi_slopes_batch_stride", ctypes.c_int64),
+        ("kv_batch_idx", ctypes.c_void_p),
     ]
+
+
+class FaKvcacheAppendParams(ctypes.Structure):
+    """Field-for-field mirror of `struct fa_kvcache_append_params` (include/fa_fwd.h)."""
+
+    _fields_ = (
+        [("abi_version", ctypes.c_uint32), ("struct_size", ctypes.c_uint32)]
+        + [(n, ctypes.c_void_p) for n in ("k_new", "v_new", "k_cache", "v_cache")]
+        + [(f"{t}_{s}_stride", ctypes.c_int64) for t in ("knew", "vnew", "kcache", "vcache")
+           for s in ("batch", "row", "head")]
+        + [(n, ctypes.c_int32) for n in ("b", "seqlen_new", "seqlen_cache", "h_k", "d", "reserved")]
+        + [("cache_seqlens", ctypes.c_void_p), ("cache_batch_idx", ctypes.c_void_p)]
+    )
 
 
 class FaBwdParams(ctypes.Structure):
@@ -160,6 +176,12 @@ def load():
     lib.fa_fwd_tile_shape.restype = ctypes.c_int
     lib.fa_set_default_variant.argtypes = [ctypes.c_int32]
     lib.fa_set_default_variant.restype = None
+    lib.fa_kvcache_append.argtypes = [ctypes.POINTER(FaKvcacheAppendParams), ctypes.c_void_p]
+    lib.fa_kvcache_append.restype = ctypes.c_int
+    lib.fa_kvcache_append_params_size.argtypes = []
+    lib.fa_kvcache_append_params_size.restype = ctypes.c_uint32
+    if lib.fa_kvcache_append_params_size() != ctypes.sizeof(FaKvcacheAppendParams):
+        raise RuntimeError("fa_kvcache_append_params layout mismatch between include/fa_fwd.h and _lib")
     lib.fa_bwd.argtypes = [ctypes.POINTER(FaBwdParams), ctypes.c_void_p]
     lib.fa_bwd.restype = ctypes.c_int
     lib.fa_bwd_validate.argtypes = [ctypes.POINTER(FaBwdParams)]

@@ -47,6 +47,30 @@ __global__ void expand_fp8_kernel(const uint8_t *__restrict__ src, uint32_t *__r
     }
 }
 
+// ---- KV-cache append: k_new/v_new rows -> cache rows [cache_seqlens[b], +seqlen_new).  One thread = one 16-byte chunk
+// of K and the same chunk of V.  HBM-bound elementwise pass.
+__global__ void kvcache_append_kernel(const fa_kvcache_append_params p) {
+    const int chunks = p.d >> 3;
+    const int64_t total = (int64_t)p.b * p.seqlen_new * p.h_k * chunks;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % chunks);
+        int64_t t = i / chunks;
+        const int hd = (int)(t % p.h_k);
+        t /= p.h_k;
+        const int row = (int)(t % p.seqlen_new);
+        const int b = (int)(t / p.seqlen_new);
+        const int dst_row = p.cache_seqlens[b] + row;
+        if (dst_row < 0 || dst_row >= p.seqlen_cache) continue;
+        const int cb = p.cache_batch_idx ? p.cache_batch_idx[b] : b;
+        const uint16_t *ks = (const uint16_t *)p.k_new + b * p.knew_batch_stride + row * p.knew_row_stride + hd * p.knew_head_stride + c * 8;
+        const uint16_t *vs = (const uint16_t *)p.v_new + b * p.vnew_batch_stride + row * p.vnew_row_stride + hd * p.vnew_head_stride + c * 8;
+        uint16_t *kd = (uint16_t *)p.k_cache + cb * p.kcache_batch_stride + dst_row * p.kcache_row_stride + hd * p.kcache_head_stride + c * 8;
+        uint16_t *vd = (uint16_t *)p.v_cache + cb * p.vcache_batch_stride + dst_row * p.vcache_row_stride + hd * p.vcache_head_stride + c * 8;
+        *reinterpret_cast<uint4 *>(kd) = *reinterpret_cast<const uint4 *>(ks);
+        *reinterpret_cast<uint4 *>(vd) = *reinterpret_cast<const uint4 *>(vs);
+    }
+}
+
 int64_t align256(int64_t x) { return (x + 255) & ~int64_t(255); }
 
 struct Fp8Plan {
@@ -172,6 +196,30 @@ int fa_fwd_tile_shape(int32_t d, int32_t dtype, int32_t is_causal, int32_t *bloc
     return FA_OK;
 }
 
+uint32_t fa_kvcache_append_params_size(void) { return (uint32_t)sizeof(fa_kvcache_append_params); }
+
+int fa_kvcache_append(const fa_kvcache_append_params *p, void *stream_) {
+    if (!p) return FA_ERR_NULL_POINTER;
+    if (p->abi_version != FA_ABI_VERSION || p->struct_size != sizeof(fa_kvcache_append_params)) return FA_ERR_BAD_ABI;
+    if (p->b <= 0 || p->h_k <= 0 || p->seqlen_new < 0 || p->seqlen_cache < 0) return FA_ERR_BAD_SHAPE;
+    if (p->d <= 0 || p->d > 256 || p->d % 8 != 0) return FA_ERR_BAD_HEAD_DIM;
+    if (p->seqlen_new == 0) return FA_OK;
+    if (!p->k_new || !p->v_new || !p->k_cache || !p->v_cache || !p->cache_seqlens) return FA_ERR_NULL_POINTER;
+    const int64_t strides[] = {p->knew_batch_stride, p->knew_row_stride, p->knew_head_stride, p->vnew_batch_stride,
+                               p->vnew_row_stride, p->vnew_head_stride, p->kcache_batch_stride, p->kcache_row_stride,
+                               p->kcache_head_stride, p->vcache_batch_stride, p->vcache_row_stride, p->vcache_head_stride};
+    for (int64_t s : strides)
+        if (s % 8 != 0) return FA_ERR_BAD_STRIDE;
+    const void *ptrs[] = {p->k_new, p->v_new, p->k_cache, p->v_cache};
+    for (const void *ptr : ptrs)
+        if (reinterpret_cast<uintptr_t>(ptr) % 16 != 0) return FA_ERR_BAD_STRIDE;
+    const int64_t total = (int64_t)p->b * p->seqlen_new * p->h_k * (p->d / 8);
+    const int blocks = (int)std::min<int64_t>((total + 255) / 256, 256 * 8);
+    hipLaunchKernelGGL(kvcache_append_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream_), *p);
+    if (hipGetLastError() != hipSuccess) return FA_ERR_LAUNCH;
+    return FA_OK;
+}
+
 int64_t fa_fwd_workspace_size(const fa_fwd_params *p) {
     if (!p) return FA_ERR_NULL_POINTER;
     if (p->abi_version != FA_ABI_VERSION || p->struct_size != sizeof(fa_fwd_params)) return FA_ERR_BAD_ABI;
@@ -223,6 +271,7 @@ int fa_fwd_validate(const fa_fwd_params *p) {
     if (p->alibi_slopes && (reinterpret_cast<uintptr_t>(p->alibi_slopes) % 4 != 0 || p->alibi_slopes_batch_stride < 0 ||
                             p->alibi_slopes_batch_stride > 0x7fffffff))
         return FA_ERR_BAD_STRIDE;
+    if (p->kv_batch_idx && (p->cu_seqlens_q || fp8)) return FA_ERR_UNSUPPORTED;  // dense 16-bit caches only
     return FA_OK;
 }
 
@@ -305,6 +354,7 @@ int fa_fwd(const fa_fwd_params *p, void *stream_) {
 
     kp.alibi = p->alibi_slopes;
     kp.alibi_bs = (int32_t)p->alibi_slopes_batch_stride;
+    kp.kv_batch_idx = p->cu_seqlens_q ? nullptr : p->kv_batch_idx;
 
     const bool softcap = p->softcap > 0.f;
     constexpr float kLog2e = 1.4426950408889634f;

@@ -64,6 +64,7 @@ struct KParams {
     int32_t qd_bs, qd_hs, kd_bs, kd_hs, vd_bs, vd_hs;  // element strides (batch, head)
     const float *alibi;    // ALiBi slopes (h) or (b, h), NULL = off
     int32_t alibi_bs;      // batch stride of alibi (0 for the (h) form)
+    const int32_t *kv_batch_idx;  // KV-cache decode: cache entry of each batch row (NULL = identity), dense only
 };
 
 // per-workgroup effective scales for (batch, kv_head)
@@ -228,8 +229,9 @@ __global__ __launch_bounds__(NWAVES * 64, (D <= 128 ? 2 : 1)) void fwd_kernel(co
         v_base = (int64_t)k0 * p.v_row_stride;
     } else {
         sk = p.seqused_k ? p.seqused_k[batch] : p.seqlen_k;
-        k_base = (int64_t)batch * p.k_batch_stride;
-        v_base = (int64_t)batch * p.v_batch_stride;
+        const int kv_batch = p.kv_batch_idx ? p.kv_batch_idx[batch] : batch;
+        k_base = (int64_t)kv_batch * p.k_batch_stride;
+        v_base = (int64_t)kv_batch * p.v_batch_stride;
     }
     const int row_lo = m_block * BLOCK_M;
     if (row_lo >= sq) return;  // whole workgroup: nothing to do (varlen / padded grid)

@@ -375,8 +375,9 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
         v_base = (int64_t)k0 * p.v_row_stride;
     } else {
         sk = p.seqused_k ? p.seqused_k[batch] : p.seqlen_k;
-        k_base = (int64_t)batch * p.k_batch_stride;
-        v_base = (int64_t)batch * p.v_batch_stride;
+        const int kv_batch = p.kv_batch_idx ? p.kv_batch_idx[batch] : batch;
+        k_base = (int64_t)kv_batch * p.k_batch_stride;
+        v_base = (int64_t)kv_batch * p.v_batch_stride;
     }
     const int row_lo = m_block * BLOCK_M;
     if (row_lo >= sq) return;

@@ -10,7 +10,7 @@ checks, output allocation, params — and enqueue the gfx950 kernel through the 
 `TORCH_CHECK` messages, raised as RuntimeError like c10::Error is.
 
 `bwd` / `varlen_bwd` do the same for mha_bwd (:767-971) / mha_varlen_bwd (:973-1200) through include/fa_bwd.h.
-`fwd_kvcache` (decode path) is not built and raises.
+`fwd_kvcache` covers the decode path (mha_fwd_kvcache :1202-1476) without rotary / paged KV / split-KV.
 """
 import math
 from typing import List, Optional
@@ -356,6 +356,114 @@ def varlen_bwd(dout: torch.Tensor, q: torch.Tensor, k: torch.Tensor, v: torch.Te
     return [dq, dk, dv, softmax_d]
 
 
-def fwd_kvcache(*args, **kwargs):
-    """mha_fwd_kvcache, csrc/flash_attn/flash_api.cpp:1202 — decode path, not built."""
-    raise RuntimeError("flash_attn_2_cuda.fwd_kvcache: the KV-cache decode path is not built in this back-end")
+def fwd_kvcache(q: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor, k_: Optional[torch.Tensor],
+                v_: Optional[torch.Tensor], seqlens_k_: Optional[torch.Tensor], rotary_cos_: Optional[torch.Tensor],
+                rotary_sin_: Optional[torch.Tensor], cache_batch_idx_: Optional[torch.Tensor],
+                leftpad_k_: Optional[torch.Tensor], block_table_: Optional[torch.Tensor],
+                alibi_slopes_: Optional[torch.Tensor], out_: Optional[torch.Tensor], softmax_scale: float,
+                is_causal: bool, window_size_left: int, window_size_right: int, softcap: float,
+                is_rotary_interleaved: bool, num_splits: int) -> List[torch.Tensor]:
+    """mha_fwd_kvcache, csrc/flash_attn/flash_api.cpp:1202-1476.  Returns [out, softmax_lse].
+
+    Built: in-place append of k_/v_ at seqlens_k_, attention over the first seqlens_k_ (+ appended) rows of each
+    cache entry, cache_batch_idx_, causal / window / softcap / ALiBi, the (b, 1, h) -> (b, ngroups, h_k) GQA swap
+    (:1277-1285).  num_splits is a performance hint and is ignored (no split-KV).  Rotary embedding, paged KV
+    (block_table_) and leftpad_k_ are rejected by message."""
+    _lib.load()
+    q_dtype = q.dtype
+    _check(q_dtype in (torch.float16, torch.bfloat16), "FlashAttention only support fp16 and bf16 data type")
+    _check(kcache.dtype == q_dtype, "query and key must have the same dtype")
+    _check(vcache.dtype == q_dtype, "query and value must have the same dtype")
+    _check_device(q, "q"); _check_device(kcache, "kcache"); _check_device(vcache, "vcache")
+    for t in (q, kcache, vcache):
+        _check(t.stride(-1) == 1, "Input tensor must have contiguous last dimension")
+    _check(block_table_ is None, "This flash attention build does not support paged KV.")
+    _check(leftpad_k_ is None, "This flash attention build does not support leftpad_k.")
+    _check(rotary_cos_ is None and rotary_sin_ is None, "This flash attention build does not support rotary embedding in fwd_kvcache.")
+
+    batch_size, seqlen_q, num_heads, head_size_og = q.shape
+    batch_size_c, seqlen_k, num_heads_k = kcache.shape[0], kcache.shape[1], kcache.shape[2]
+    _check(batch_size > 0, "batch size must be positive")
+    _check(head_size_og <= 256, "FlashAttention forward only supports head dimension at most 256")
+    _check(head_size_og % 8 == 0, "This flash attention build needs head_size to be a multiple of 8 in fwd_kvcache")
+    _check(num_heads % num_heads_k == 0, "Number of heads in key/value must divide number of heads in query")
+    alibi = _check_alibi(alibi_slopes_, batch_size, num_heads)
+
+    if seqlen_q == 1 and alibi is None:
+        is_causal = False  # (:1270)
+    if is_causal:
+        window_size_right = 0
+    # (b, 1, (h_k ngroups), d) -> (b, ngroups, h_k, d): one pass over the cache serves the whole GQA group (:1272-1285)
+    swapped = (seqlen_q == 1 and num_heads > num_heads_k and window_size_left < 0 and window_size_right < 0
+               and alibi is None)
+    if swapped:
+        ngroups = num_heads // num_heads_k
+        q = q.reshape(batch_size, num_heads_k, ngroups, head_size_og).transpose(1, 2)
+        seqlen_q, num_heads = ngroups, num_heads_k
+
+    _check_shape(q, "q", batch_size, seqlen_q, num_heads, head_size_og)
+    _check_shape(kcache, "kcache", batch_size_c, seqlen_k, num_heads_k, head_size_og)
+    _check_shape(vcache, "vcache", batch_size_c, seqlen_k, num_heads_k, head_size_og)
+
+    if out_ is not None and not swapped:
+        out = out_
+        _check(out.dtype == q_dtype, "Output must have the same dtype as inputs")
+        _check_device(out, "out")
+        _check(out.stride(-1) == 1, "Output tensor must have contiguous last dimension")
+        _check_shape(out, "out", batch_size, seqlen_q, num_heads, head_size_og)
+    else:
+        out = torch.empty((batch_size, seqlen_q, num_heads, head_size_og), dtype=q_dtype, device=q.device)
+
+    seqlen_knew = 0
+    if k_ is not None:
+        _check(v_ is not None, "If key is supplied, value must also be passed in")
+        _check(seqlens_k_ is not None, "If key is supplied, seqlens_k must also be passed in")
+        _check(seqlen_q <= seqlen_k, "If key is supplied, it must have seqlen <= the seqlen of the KV cache")
+        _check(k_.dtype == q_dtype, "Key must have the same dtype as query")
+        _check(v_.dtype == q_dtype, "Value must have the same dtype as query")
+        _check_device(k_, "k"); _check_device(v_, "v")
+        _check(k_.stride(-1) == 1, "Key tensor must have contiguous last dimension")
+        _check(v_.stride(-1) == 1, "Value tensor must have contiguous last dimension")
+        seqlen_knew = k_.shape[1]
+        _check_shape(k_, "k", batch_size, seqlen_knew, num_heads_k, head_size_og)
+        _check_shape(v_, "v", batch_size, seqlen_knew, num_heads_k, head_size_og)
+    if seqlens_k_ is not None:
+        _check(seqlens_k_.dtype == torch.int32, "seqlens_k must have dtype int32")
+        _check_device(seqlens_k_, "seqlens_k")
+        _check(seqlens_k_.is_contiguous(), "seqlens_k must be contiguous")
+        _check_shape(seqlens_k_, "seqlens_k", batch_size)
+    if cache_batch_idx_ is not None:
+        _check_device(cache_batch_idx_, "cache_batch_idx")
+        _check(cache_batch_idx_.is_contiguous(), "cache_batch_idx must be contiguous")
+        _check(cache_batch_idx_.dtype == torch.int32, "cache_batch_idx must have dtype int32")
+    else:
+        _check(batch_size_c >= batch_size, "the KV cache must have at least batch_size entries")
+    for t in (kcache, vcache):
+        _check(_aligned(t), "the KV cache must be 16-byte aligned with row/head/batch strides that are multiples of 8")
+
+    with torch.cuda.device(q.device):
+        softmax_lse = torch.empty((batch_size, num_heads, seqlen_q), dtype=torch.float32, device=q.device)
+        seqused = seqlens_k_
+        if seqlen_knew > 0:  # "Append_KV": new rows land at [seqlens_k, seqlens_k + seqlen_knew) of each cache entry
+            kn, vn = (x if _aligned(x) else x.contiguous() for x in (k_, v_))
+            _dispatch.kvcache_append(kn, vn, kcache, vcache, seqlens_k_, cache_batch_idx_)
+            seqused = seqlens_k_ + seqlen_knew
+        qc = q if _aligned(q) else q.contiguous()
+        oc = out if _aligned(out) else torch.empty_like(out, memory_format=torch.contiguous_format)
+        if seqlen_k > 0:
+            _dispatch.launch(qc, kcache, vcache, oc, softmax_lse, varlen=False, batch=batch_size,
+                             max_seqlen_q=seqlen_q, max_seqlen_k=seqlen_k, softmax_scale=softmax_scale,
+                             causal=is_causal, window_left=window_size_left, window_right=window_size_right,
+                             softcap=softcap, seqused_k=seqused, alibi_slopes=alibi, kv_batch_idx=cache_batch_idx_)
+            if oc is not out:
+                out.copy_(oc)
+        else:
+            out.zero_()
+            softmax_lse.fill_(math.inf)
+    if swapped:
+        out = out.transpose(1, 2).reshape(batch_size, 1, num_heads_k * seqlen_q, head_size_og)
+        softmax_lse = softmax_lse.reshape(batch_size, num_heads_k * seqlen_q, 1)
+        if out_ is not None:
+            out_.copy_(out)
+            out = out_
+    return [out, softmax_lse]

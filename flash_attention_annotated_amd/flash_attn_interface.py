@@ -310,3 +310,31 @@ def flash_attn_varlen_kvpacked_func(q, kv, cu_seqlens_q, cu_seqlens_k, max_seqle
     return flash_attn_varlen_func(q, kv[:, 0], kv[:, 1], cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k,
                                   dropout_p, softmax_scale, causal, window_size, softcap, alibi_slopes,
                                   deterministic, return_attn_probs)
+
+
+def flash_attn_with_kvcache(q, k_cache, v_cache, k=None, v=None, rotary_cos=None, rotary_sin=None, cache_seqlens=None,
+                            cache_batch_idx=None, cache_leftpad=None, block_table=None, softmax_scale=None,
+                            causal=False, window_size=(-1, -1), softcap=0.0, rotary_interleaved=True,
+                            alibi_slopes=None, num_splits=0, return_softmax_lse=False):
+    """reference :1474-1616.  q: (batch, seqlen_q, nheads, headdim); k_cache, v_cache: (batch_cache, seqlen_cache,
+    nheads_k, headdim).  If k / v are given they are written IN PLACE into the caches at rows
+    [cache_seqlens, cache_seqlens + seqlen_new) and attention runs over the updated cache (incremental decoding).
+    cache_seqlens: int or (batch,) int32; cache_batch_idx: (batch,) int32 indices into the cache.
+    Causal / window masks are aligned to the bottom-right corner of each (seqlen_q, cache_seqlens + seqlen_new) block.
+    Not built (rejected by message): rotary_cos/sin, block_table (paged KV), cache_leftpad; num_splits is ignored.
+    Returns out (batch, seqlen_q, nheads, headdim) [, softmax_lse (batch, nheads, seqlen_q)]."""
+    assert k_cache.stride(-1) == 1, "k_cache must have contiguous last dimension"
+    assert v_cache.stride(-1) == 1, "v_cache must have contiguous last dimension"
+    q, k, v = [maybe_contiguous(x) for x in (q, k, v)]
+    if softmax_scale is None:
+        softmax_scale = q.shape[-1] ** (-0.5)
+    if cache_seqlens is not None and isinstance(cache_seqlens, int):
+        cache_seqlens = torch.full((q.shape[0],), cache_seqlens, dtype=torch.int32, device=k_cache.device)
+        cache_seqlens = maybe_contiguous(cache_seqlens)
+    cache_batch_idx = maybe_contiguous(cache_batch_idx)
+    block_table = maybe_contiguous(block_table)
+    out, softmax_lse = flash_attn_gpu.fwd_kvcache(
+        q, k_cache, v_cache, k, v, cache_seqlens, rotary_cos, rotary_sin, cache_batch_idx, cache_leftpad, block_table,
+        alibi_slopes, None, softmax_scale, causal, window_size[0], window_size[1], softcap, rotary_interleaved,
+        num_splits)
+    return (out, softmax_lse) if return_softmax_lse else out

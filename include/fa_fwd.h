@@ -15,6 +15,7 @@
  *                    hopper/flash.h:37-168                        fa_fwd_params
  *   flash_attention_forward(FlashAttentionParams&, cudaStream_t)
  *                    standalone/include/flash_api.h:222-225       fa_fwd(const fa_fwd_params*, void*)
+ *   mha_fwd_kvcache  csrc/flash_attn/flash_api.cpp:1202-1476      fa_kvcache_append + fa_fwd (seqused_k, kv_batch_idx)
  *   error codes      standalone/src/flash_api.cu:403-426          FA_ERR_* / fa_strerror
  *
  * Conventions (same as the reference's params struct):
@@ -37,7 +38,7 @@
 extern "C" {
 #endif
 
-#define FA_ABI_VERSION 3
+#define FA_ABI_VERSION 4
 
 /* element types of q/k/v (o has the same type; fp8 inputs produce bf16 o) */
 enum fa_dtype {
@@ -131,6 +132,11 @@ typedef struct fa_fwd_params {
      * differs from the reference kernel's  +slope * j  only by a per-row constant (same O; LSE includes the bias). */
     const float *alibi_slopes;
     int64_t alibi_slopes_batch_stride;
+
+    /* KV-cache decode (mha_fwd_kvcache csrc/flash_attn/flash_api.cpp:1202-1476; FA3 kv_batch_idx
+     * hopper/flash_api.cpp:686): dense layout only; batch i reads k/v rows of cache entry kv_batch_idx[i]
+     * (NULL = i).  The valid length of each cache entry is given through seqused_k. */
+    const int32_t *kv_batch_idx;
 } fa_fwd_params;
 
 /* Validate and enqueue the forward on `stream` (a hipStream_t; NULL = default
@@ -155,6 +161,32 @@ uint32_t fa_abi_version(void);
 /* Tile geometry chosen for (d, dtype, causal): writes block_m / block_n.
  * Role of tile_size_fwd_sm90 (hopper/tile_size.h:10-54). */
 int fa_fwd_tile_shape(int32_t d, int32_t dtype, int32_t is_causal, int32_t *block_m, int32_t *block_n);
+
+/*
+ * In-place append of new keys/values to a KV cache -- the "Append_KV" step of mha_fwd_kvcache
+ * (csrc/flash_attn/flash_api.cpp:1354-1382, src/flash_fwd_kernel.h:651-735), as its own HBM-bound launch:
+ * rows k_new[i, 0:seqlen_new) go to k_cache[idx(i), cache_seqlens[i] + 0:seqlen_new) (idx = cache_batch_idx or
+ * identity); rows that would fall past seqlen_cache are dropped.  16-bit elements, head_dim stride 1, d % 8 == 0.
+ */
+typedef struct fa_kvcache_append_params {
+    uint32_t abi_version; /* FA_ABI_VERSION */
+    uint32_t struct_size; /* sizeof(fa_kvcache_append_params) */
+    const void *k_new; /* (b, seqlen_new, h_k, d) */
+    const void *v_new;
+    void *k_cache;     /* (b_cache, seqlen_cache, h_k, d) */
+    void *v_cache;
+    int64_t knew_batch_stride, knew_row_stride, knew_head_stride;
+    int64_t vnew_batch_stride, vnew_row_stride, vnew_head_stride;
+    int64_t kcache_batch_stride, kcache_row_stride, kcache_head_stride;
+    int64_t vcache_batch_stride, vcache_row_stride, vcache_head_stride;
+    int32_t b, seqlen_new, seqlen_cache, h_k, d;
+    int32_t reserved;
+    const int32_t *cache_seqlens;   /* (b) int32, rows already valid in each cache entry */
+    const int32_t *cache_batch_idx; /* (b) int32 or NULL */
+} fa_kvcache_append_params;
+
+int fa_kvcache_append(const fa_kvcache_append_params *params, void *stream);
+uint32_t fa_kvcache_append_params_size(void);
 
 /* Test hook: overrides the default kernel variant process-wide (0 = default). */
 void fa_set_default_variant(int32_t variant);

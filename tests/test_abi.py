@@ -129,3 +129,28 @@ def test_bwd_validate(built_lib, mutate, code):
     assert built_lib.fa_bwd_validate(ctypes.byref(p)) == code
     if code != 0:
         assert built_lib.fa_bwd(ctypes.byref(p), None) == code
+
+
+def test_kvcache_append_validate(built_lib):
+    """fa_kvcache_append (include/fa_fwd.h): rejected before launch with the documented codes."""
+    p = _lib.FaKvcacheAppendParams()
+    p.abi_version = _lib.FA_ABI_VERSION
+    p.struct_size = ctypes.sizeof(_lib.FaKvcacheAppendParams)
+    assert built_lib.fa_kvcache_append_params_size() == ctypes.sizeof(_lib.FaKvcacheAppendParams)
+    p.b, p.seqlen_new, p.seqlen_cache, p.h_k, p.d = 2, 1, 128, 2, 64
+    for f in ("k_new", "v_new", "k_cache", "v_cache", "cache_seqlens"):
+        setattr(p, f, 0x10000)
+    for t in ("knew", "vnew", "kcache", "vcache"):
+        setattr(p, f"{t}_row_stride", 128)
+        setattr(p, f"{t}_head_stride", 64)
+        setattr(p, f"{t}_batch_stride", 128 * 128)
+    p.d = 60
+    assert built_lib.fa_kvcache_append(ctypes.byref(p), None) == -3
+    p.d = 64
+    p.kcache_row_stride = 100
+    assert built_lib.fa_kvcache_append(ctypes.byref(p), None) == -6
+    p.kcache_row_stride = 128
+    p.cache_seqlens = 0
+    assert built_lib.fa_kvcache_append(ctypes.byref(p), None) == -1
+    p.abi_version = 1
+    assert built_lib.fa_kvcache_append(ctypes.byref(p), None) == -9

@@ -41,8 +41,11 @@ def test_extension_module_surface():
     assert top_level_alias.fwd is flash_attn_2_cuda.fwd
     assert len(inspect.signature(flash_attn_2_cuda.bwd).parameters) == 19          # :767-786
     assert len(inspect.signature(flash_attn_2_cuda.varlen_bwd).parameters) == 24   # :973-997
-    with pytest.raises(RuntimeError, match="not built"):
-        flash_attn_2_cuda.fwd_kvcache()
+    assert len(inspect.signature(flash_attn_2_cuda.fwd_kvcache).parameters) == 20  # :1202-1222
+    assert [n for n, _ in _params(fa.flash_attn_with_kvcache)] == [
+        "q", "k_cache", "v_cache", "k", "v", "rotary_cos", "rotary_sin", "cache_seqlens", "cache_batch_idx",
+        "cache_leftpad", "block_table", "softmax_scale", "causal", "window_size", "softcap", "rotary_interleaved",
+        "alibi_slopes", "num_splits", "return_softmax_lse"]  # flash_attn/flash_attn_interface.py:1474-1494
 
 
 def test_no_cpu_fallback():
