@@ -26,19 +26,24 @@ def aligned(t):
 
 def launch(q, k, v, out, lse, *, varlen, batch, max_seqlen_q, max_seqlen_k, softmax_scale, causal, window_left,
            window_right, softcap, cu_seqlens_q=None, cu_seqlens_k=None, seqused_q=None, seqused_k=None,
-           q_descale=None, k_descale=None, v_descale=None, alibi_slopes=None, kv_batch_idx=None):
+           q_descale=None, k_descale=None, v_descale=None, alibi_slopes=None, kv_batch_idx=None, block_table=None):
     """q/k/v/out: dense (b, s, h, d) or packed (total, h, d) tensors on one GPU, last stride 1, aligned()."""
     lib = _lib.load()
     prm = _lib.new_params()
     prm.q, prm.k, prm.v, prm.o = ptr(q), ptr(k), ptr(v), ptr(out)
     prm.softmax_lse = ptr(lse)
     if varlen:
-        for name, t in (("q", q), ("k", k), ("v", v), ("o", out)):
+        for name, t in (("q", q), ("o", out)) + ((() if block_table is not None else (("k", k), ("v", v)))):
             setattr(prm, f"{name}_batch_stride", 0)
             setattr(prm, f"{name}_row_stride", t.stride(0))
             setattr(prm, f"{name}_head_stride", t.stride(1))
-        prm.total_q, prm.total_k = q.shape[0], k.shape[0]
-        prm.h, prm.h_k, prm.d = q.shape[1], k.shape[1], q.shape[2]
+        if block_table is not None:  # k, v: (num_blocks, page_block_size, h_k, d)
+            for name, t in (("k", k), ("v", v)):
+                setattr(prm, f"{name}_batch_stride", t.stride(0))
+                setattr(prm, f"{name}_row_stride", t.stride(1))
+                setattr(prm, f"{name}_head_stride", t.stride(2))
+        prm.total_q, prm.total_k = q.shape[0], (0 if block_table is not None else k.shape[0])
+        prm.h, prm.h_k, prm.d = q.shape[1], k.shape[-2], q.shape[2]
     else:
         for name, t in (("q", q), ("k", k), ("v", v), ("o", out)):
             setattr(prm, f"{name}_batch_stride", t.stride(0))
@@ -63,6 +68,10 @@ def launch(q, k, v, out, lse, *, varlen, batch, max_seqlen_q, max_seqlen_k, soft
         prm.alibi_slopes = ptr(alibi_slopes)
         prm.alibi_slopes_batch_stride = alibi_slopes.stride(0) if alibi_slopes.dim() == 2 else 0
     prm.kv_batch_idx = ptr(kv_batch_idx)
+    if block_table is not None:
+        prm.block_table = ptr(block_table)
+        prm.block_table_batch_stride = block_table.stride(0)
+        prm.page_block_size = k.shape[1]
     workspace = None
     need = lib.fa_fwd_workspace_size(ctypes.byref(prm))
     if need < 0:
@@ -124,7 +133,7 @@ def launch_bwd(dout, q, k, v, out, lse, dq, dk, dv, softmax_d, *, varlen, batch,
         raise RuntimeError(f"fa_bwd failed ({st}): {_lib.strerror(st)}")
 
 
-def kvcache_append(k_new, v_new, k_cache, v_cache, cache_seqlens, cache_batch_idx=None):
+def kvcache_append(k_new, v_new, k_cache, v_cache, cache_seqlens, cache_batch_idx=None, block_table=None):
     """(b, s_new, h_k, d) rows appended in place to (b_cache, s_cache, h_k, d) caches at cache_seqlens (int32, (b,))."""
     lib = _lib.load()
     prm = _lib.FaKvcacheAppendParams()
@@ -137,6 +146,11 @@ def kvcache_append(k_new, v_new, k_cache, v_cache, cache_seqlens, cache_batch_id
         setattr(prm, f"{name}_head_stride", t.stride(2))
     prm.b, prm.seqlen_new, prm.h_k, prm.d = k_new.shape
     prm.seqlen_cache = k_cache.shape[1]
+    if block_table is not None:
+        prm.block_table = ptr(block_table)
+        prm.block_table_batch_stride = block_table.stride(0)
+        prm.page_block_size = k_cache.shape[1]
+        prm.seqlen_cache = block_table.shape[1] * k_cache.shape[1]
     prm.cache_seqlens = ptr(cache_seqlens)
     prm.cache_batch_idx = ptr(cache_batch_idx)
     stream = torch.cuda.current_stream(k_new.device).cuda_stream

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, LIB_NAME)
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
-FA_ABI_VERSION = 4
+FA_ABI_VERSION = 5
 FA_DTYPE_FP16, FA_DTYPE_BF16, FA_DTYPE_FP8_E4M3 = 0, 1, 2
 
 # every symbol include/fa_fwd.h declares (tests check the .so exports all of them)
@@ -92,6 +92,10 @@ class FaFwdParams(ctypes.Structure):
         ("alibi_slopes", ctypes.c_void_p),
         ("alibi_slopes_batch_stride", ctypes.c_int64),
         ("kv_batch_idx", ctypes.c_void_p),
+        ("block_table", ctypes.c_void_p),
+        ("block_table_batch_stride", ctypes.c_int64),
+        ("page_block_size", ctypes.c_int32),
+        ("reserved0", ctypes.c_int32),
     ]
 
 
@@ -105,6 +109,8 @@ class FaKvcacheAppendParams(ctypes.Structure):
            for s in ("batch", "row", "head")]
         + [(n, ctypes.c_int32) for n in ("b", "seqlen_new", "seqlen_cache", "h_k", "d", "reserved")]
         + [("cache_seqlens", ctypes.c_void_p), ("cache_batch_idx", ctypes.c_void_p)]
+        + [("block_table", ctypes.c_void_p), ("block_table_batch_stride", ctypes.c_int64),
+           ("page_block_size", ctypes.c_int32), ("reserved1", ctypes.c_int32)]
     )
 
 

@@ -59,9 +59,13 @@ __global__ void kvcache_append_kernel(const fa_kvcache_append_params p) {
         t /= p.h_k;
         const int row = (int)(t % p.seqlen_new);
         const int b = (int)(t / p.seqlen_new);
-        const int dst_row = p.cache_seqlens[b] + row;
+        int dst_row = p.cache_seqlens[b] + row;
         if (dst_row < 0 || dst_row >= p.seqlen_cache) continue;
-        const int cb = p.cache_batch_idx ? p.cache_batch_idx[b] : b;
+        int cb = p.cache_batch_idx ? p.cache_batch_idx[b] : b;
+        if (p.block_table) {
+            cb = p.block_table[b * p.block_table_batch_stride + dst_row / p.page_block_size];
+            dst_row %= p.page_block_size;
+        }
         const uint16_t *ks = (const uint16_t *)p.k_new + b * p.knew_batch_stride + row * p.knew_row_stride + hd * p.knew_head_stride + c * 8;
         const uint16_t *vs = (const uint16_t *)p.v_new + b * p.vnew_batch_stride + row * p.vnew_row_stride + hd * p.vnew_head_stride + c * 8;
         uint16_t *kd = (uint16_t *)p.k_cache + cb * p.kcache_batch_stride + dst_row * p.kcache_row_stride + hd * p.kcache_head_stride + c * 8;
@@ -205,6 +209,7 @@ int fa_kvcache_append(const fa_kvcache_append_params *p, void *stream_) {
     if (p->d <= 0 || p->d > 256 || p->d % 8 != 0) return FA_ERR_BAD_HEAD_DIM;
     if (p->seqlen_new == 0) return FA_OK;
     if (!p->k_new || !p->v_new || !p->k_cache || !p->v_cache || !p->cache_seqlens) return FA_ERR_NULL_POINTER;
+    if (p->block_table && (p->page_block_size <= 0 || p->cache_batch_idx)) return FA_ERR_BAD_SHAPE;
     const int64_t strides[] = {p->knew_batch_stride, p->knew_row_stride, p->knew_head_stride, p->vnew_batch_stride,
                                p->vnew_row_stride, p->vnew_head_stride, p->kcache_batch_stride, p->kcache_row_stride,
                                p->kcache_head_stride, p->vcache_batch_stride, p->vcache_row_stride, p->vcache_head_stride};
@@ -272,6 +277,11 @@ int fa_fwd_validate(const fa_fwd_params *p) {
                             p->alibi_slopes_batch_stride > 0x7fffffff))
         return FA_ERR_BAD_STRIDE;
     if (p->kv_batch_idx && (p->cu_seqlens_q || fp8)) return FA_ERR_UNSUPPORTED;  // dense 16-bit caches only
+    if (p->block_table) {
+        if (fp8 || p->kv_batch_idx) return FA_ERR_UNSUPPORTED;  // "Paged KVcache does not support cache_batch_idx" (:1247)
+        if (p->page_block_size <= 0 || p->page_block_size % 256 != 0) return FA_ERR_BAD_SHAPE;  // (:1265)
+        if (p->block_table_batch_stride < 0 || p->block_table_batch_stride > 0x7fffffff) return FA_ERR_BAD_STRIDE;
+    }
     return FA_OK;
 }
 
@@ -282,6 +292,7 @@ int fa_fwd(const fa_fwd_params *p, void *stream_) {
 
     int variant = p->kernel_variant ? p->kernel_variant : g_default_variant.load();
     if (variant < 0 || variant > 3) variant = 0;
+    if (p->block_table && (variant == 0 || variant == 3)) variant = 1;  // paged caches: the 64-key-aligned tile shape
     const int block_m = block_m_of(variant, p->d);
 
     fa::KParams kp{};
@@ -355,6 +366,9 @@ int fa_fwd(const fa_fwd_params *p, void *stream_) {
     kp.alibi = p->alibi_slopes;
     kp.alibi_bs = (int32_t)p->alibi_slopes_batch_stride;
     kp.kv_batch_idx = p->cu_seqlens_q ? nullptr : p->kv_batch_idx;
+    kp.block_table = p->block_table;
+    kp.bt_bs = (int32_t)p->block_table_batch_stride;
+    kp.page_size = p->page_block_size;
 
     const bool softcap = p->softcap > 0.f;
     constexpr float kLog2e = 1.4426950408889634f;

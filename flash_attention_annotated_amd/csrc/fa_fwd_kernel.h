@@ -65,6 +65,8 @@ struct KParams {
     const float *alibi;    // ALiBi slopes (h) or (b, h), NULL = off
     int32_t alibi_bs;      // batch stride of alibi (0 for the (h) form)
     const int32_t *kv_batch_idx;  // KV-cache decode: cache entry of each batch row (NULL = identity), dense only
+    const int32_t *block_table;   // paged KV: page of key row j of batch i = block_table[i * bt_bs + j / page_size]
+    int32_t bt_bs, page_size;     // (only the fwd_kernel shape reads paged caches: its tiles are 64-key aligned)
 };
 
 // per-workgroup effective scales for (batch, kv_head)
@@ -238,6 +240,8 @@ __global__ __launch_bounds__(NWAVES * 64, (D <= 128 ? 2 : 1)) void fwd_kernel(co
     const Scales sc = load_scales(p, batch, kv_head);
     const float alibi = load_alibi(p, sc, batch, head);
 
+    if (p.block_table) k_base = v_base = 0;  // paged: the page supplies the batch offset
+    const int32_t *pages = p.block_table ? p.block_table + (int64_t)batch * p.bt_bs : nullptr;
     const T *qp = (const T *)p.q + q_base + (int64_t)head * p.q_head_stride;
     const T *kp = (const T *)p.k + k_base + (int64_t)kv_head * p.k_head_stride;
     const T *vp = (const T *)p.v + v_base + (int64_t)kv_head * p.v_head_stride;
@@ -295,6 +299,11 @@ __global__ __launch_bounds__(NWAVES * 64, (D <= 128 ? 2 : 1)) void fwd_kernel(co
         const int k0 = n * BLOCK_N;
         const T *kt = kp + (int64_t)k0 * p.k_row_stride;  // scalar
         const T *vt = vp + (int64_t)k0 * p.v_row_stride;
+        if (pages) {  // a 64-key tile lies inside one page (page_size % 256 == 0)
+            const int page = pages[k0 / p.page_size], in_page = k0 % p.page_size;
+            kt = kp + (int64_t)page * p.k_batch_stride + (int64_t)in_page * p.k_row_stride;
+            vt = vp + (int64_t)page * p.v_batch_stride + (int64_t)in_page * p.v_row_stride;
+        }
         const int last = sk - 1 - k0;                     // >= 0 for every tile in [n_min, n_max)
 #pragma unroll
         for (int i = 0; i < LD_PER_THREAD; ++i) {

@@ -63,6 +63,19 @@ def _check_alibi(alibi_slopes_, batch_size, num_heads):
     return alibi_slopes_
 
 
+def _check_block_table(block_table_, kcache, batch_size):
+    """Paged KV (csrc/flash_attn/flash_api.cpp:554-560, 1245-1266): returns (page_block_size, max_num_blocks_per_seq)."""
+    _check_device(block_table_, "block_table")
+    _check(block_table_.dtype == torch.int32, "block_table must have dtype torch.int32")
+    _check(block_table_.stride(-1) == 1, "block_table must have contiguous last dimension")
+    _check(kcache.dim() == 4, "paged k/v must have shape (num_blocks, page_block_size, num_heads_k, head_size)")
+    page_block_size = kcache.shape[1]
+    _check(page_block_size % 256 == 0, "Paged KV cache block size must be divisible by 256")
+    _check(block_table_.dim() == 2 and block_table_.shape[0] == batch_size,
+           "block_table must have shape (batch_size, max_num_blocks_per_seq)")
+    return page_block_size, block_table_.shape[1]
+
+
 def fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out_: Optional[torch.Tensor],
         alibi_slopes_: Optional[torch.Tensor], p_dropout: float, softmax_scale: float, is_causal: bool,
         window_size_left: int, window_size_right: int, softcap: float, return_softmax: bool,
@@ -144,7 +157,7 @@ def varlen_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out_: Optional
     _check(cu_seqlens_k.dtype == torch.int32, "cu_seqlens_k must have dtype int32")
     for t, n in ((q, "q"), (k, "k"), (v, "v"), (cu_seqlens_q, "cu_seqlens_q"), (cu_seqlens_k, "cu_seqlens_k")):
         _check_device(t, n)
-    _check(block_table_ is None, "This flash attention build does not support paged KV.")
+    paged = block_table_ is not None
     _check(leftpad_k_ is None, "This flash attention build does not support leftpad_k.")
     _check(q.stride(-1) == 1, "Input tensor must have contiguous last dimension")
     _check(k.stride(-1) == 1, "Input tensor must have contiguous last dimension")
@@ -154,7 +167,11 @@ def varlen_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out_: Optional
 
     total_q, num_heads, head_size = q.shape
     batch_size = cu_seqlens_q.numel() - 1
-    total_k, num_heads_k = k.shape[0], k.shape[1]
+    if paged:  # k, v: (num_blocks, page_block_size, h_k, d), rows found through block_table (:554-560, :608-612)
+        _check_block_table(block_table_, k, batch_size)
+        total_k, num_heads_k = 0, k.shape[2]
+    else:
+        total_k, num_heads_k = k.shape[0], k.shape[1]
     _check(batch_size > 0, "batch size must be positive")
     _check(head_size <= 256, "FlashAttention forward only supports head dimension at most 256")
     _check(head_size % 8 == 0, "query, key, value, and out_ must have a head_size that is a multiple of 8")
@@ -168,8 +185,12 @@ def varlen_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out_: Optional
         is_causal = False  # (:590)
 
     _check_shape(q, "q", total_q, num_heads, head_size)
-    _check_shape(k, "k", total_k, num_heads_k, head_size)
-    _check_shape(v, "v", total_k, num_heads_k, head_size)
+    if paged:
+        _check_shape(k, "k", k.shape[0], k.shape[1], num_heads_k, head_size)
+        _check_shape(v, "v", k.shape[0], k.shape[1], num_heads_k, head_size)
+    else:
+        _check_shape(k, "k", total_k, num_heads_k, head_size)
+        _check_shape(v, "v", total_k, num_heads_k, head_size)
     _check_shape(cu_seqlens_q, "cu_seqlens_q", batch_size + 1)
     _check_shape(cu_seqlens_k, "cu_seqlens_k", batch_size + 1)
     if seqused_k is not None:
@@ -202,7 +223,7 @@ def varlen_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out_: Optional
                              max_seqlen_k=max_seqlen_k, softmax_scale=softmax_scale, causal=is_causal,
                              window_left=window_size_left, window_right=window_size_right, softcap=softcap,
                              cu_seqlens_q=cu_seqlens_q, cu_seqlens_k=cu_seqlens_k, seqused_k=seqused_k,
-                             alibi_slopes=alibi)
+                             alibi_slopes=alibi, block_table=block_table_)
             if oc is not out:
                 out.copy_(oc)
         elif total_q > 0:
@@ -377,12 +398,17 @@ def fwd_kvcache(q: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor, k_:
     _check_device(q, "q"); _check_device(kcache, "kcache"); _check_device(vcache, "vcache")
     for t in (q, kcache, vcache):
         _check(t.stride(-1) == 1, "Input tensor must have contiguous last dimension")
-    _check(block_table_ is None, "This flash attention build does not support paged KV.")
+    paged = block_table_ is not None
+    if paged:
+        _check(cache_batch_idx_ is None, "Paged KVcache does not support cache_batch_idx")
     _check(leftpad_k_ is None, "This flash attention build does not support leftpad_k.")
     _check(rotary_cos_ is None and rotary_sin_ is None, "This flash attention build does not support rotary embedding in fwd_kvcache.")
 
     batch_size, seqlen_q, num_heads, head_size_og = q.shape
     batch_size_c, seqlen_k, num_heads_k = kcache.shape[0], kcache.shape[1], kcache.shape[2]
+    if paged:
+        page_block_size, max_blocks = _check_block_table(block_table_, kcache, batch_size)
+        seqlen_k, batch_size_c = max_blocks * page_block_size, batch_size  # (:1266-1268)
     _check(batch_size > 0, "batch size must be positive")
     _check(head_size_og <= 256, "FlashAttention forward only supports head dimension at most 256")
     _check(head_size_og % 8 == 0, "This flash attention build needs head_size to be a multiple of 8 in fwd_kvcache")
@@ -402,8 +428,12 @@ def fwd_kvcache(q: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor, k_:
         seqlen_q, num_heads = ngroups, num_heads_k
 
     _check_shape(q, "q", batch_size, seqlen_q, num_heads, head_size_og)
-    _check_shape(kcache, "kcache", batch_size_c, seqlen_k, num_heads_k, head_size_og)
-    _check_shape(vcache, "vcache", batch_size_c, seqlen_k, num_heads_k, head_size_og)
+    if paged:
+        _check_shape(kcache, "kcache", kcache.shape[0], page_block_size, num_heads_k, head_size_og)
+        _check_shape(vcache, "vcache", kcache.shape[0], page_block_size, num_heads_k, head_size_og)
+    else:
+        _check_shape(kcache, "kcache", batch_size_c, seqlen_k, num_heads_k, head_size_og)
+        _check_shape(vcache, "vcache", batch_size_c, seqlen_k, num_heads_k, head_size_og)
 
     if out_ is not None and not swapped:
         out = out_
@@ -446,7 +476,7 @@ def fwd_kvcache(q: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor, k_:
         seqused = seqlens_k_
         if seqlen_knew > 0:  # "Append_KV": new rows land at [seqlens_k, seqlens_k + seqlen_knew) of each cache entry
             kn, vn = (x if _aligned(x) else x.contiguous() for x in (k_, v_))
-            _dispatch.kvcache_append(kn, vn, kcache, vcache, seqlens_k_, cache_batch_idx_)
+            _dispatch.kvcache_append(kn, vn, kcache, vcache, seqlens_k_, cache_batch_idx_, block_table_)
             seqused = seqlens_k_ + seqlen_knew
         qc = q if _aligned(q) else q.contiguous()
         oc = out if _aligned(out) else torch.empty_like(out, memory_format=torch.contiguous_format)
@@ -454,7 +484,8 @@ def fwd_kvcache(q: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor, k_:
             _dispatch.launch(qc, kcache, vcache, oc, softmax_lse, varlen=False, batch=batch_size,
                              max_seqlen_q=seqlen_q, max_seqlen_k=seqlen_k, softmax_scale=softmax_scale,
                              causal=is_causal, window_left=window_size_left, window_right=window_size_right,
-                             softcap=softcap, seqused_k=seqused, alibi_slopes=alibi, kv_batch_idx=cache_batch_idx_)
+                             softcap=softcap, seqused_k=seqused, alibi_slopes=alibi, kv_batch_idx=cache_batch_idx_,
+                             block_table=block_table_)
             if oc is not out:
                 out.copy_(oc)
         else:

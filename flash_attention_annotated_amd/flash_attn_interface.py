@@ -321,7 +321,9 @@ def flash_attn_with_kvcache(q, k_cache, v_cache, k=None, v=None, rotary_cos=None
     [cache_seqlens, cache_seqlens + seqlen_new) and attention runs over the updated cache (incremental decoding).
     cache_seqlens: int or (batch,) int32; cache_batch_idx: (batch,) int32 indices into the cache.
     Causal / window masks are aligned to the bottom-right corner of each (seqlen_q, cache_seqlens + seqlen_new) block.
-    Not built (rejected by message): rotary_cos/sin, block_table (paged KV), cache_leftpad; num_splits is ignored.
+    block_table: (batch, max_blocks_per_seq) int32 for a paged cache (k_cache, v_cache: (num_blocks, page_block_size,
+    nheads_k, headdim), page_block_size % 256 == 0).
+    Not built (rejected by message): rotary_cos/sin, cache_leftpad; num_splits is ignored.
     Returns out (batch, seqlen_q, nheads, headdim) [, softmax_lse (batch, nheads, seqlen_q)]."""
     assert k_cache.stride(-1) == 1, "k_cache must have contiguous last dimension"
     assert v_cache.stride(-1) == 1, "v_cache must have contiguous last dimension"

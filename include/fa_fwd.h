@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define FA_ABI_VERSION 4
+#define FA_ABI_VERSION 5
 
 /* element types of q/k/v (o has the same type; fp8 inputs produce bf16 o) */
 enum fa_dtype {
@@ -137,6 +137,15 @@ typedef struct fa_fwd_params {
      * hopper/flash_api.cpp:686): dense layout only; batch i reads k/v rows of cache entry kv_batch_idx[i]
      * (NULL = i).  The valid length of each cache entry is given through seqused_k. */
     const int32_t *kv_batch_idx;
+
+    /* Paged KV cache (csrc/flash_attn/flash_api.cpp:1245-1266, 538-560; src/flash_fwd_kernel.h:560-576): k and v are
+     * (num_blocks, page_block_size, h_k, d) -- k/v_batch_stride is the page stride -- and key row j of batch i lives in
+     * page block_table[i * block_table_batch_stride + j / page_block_size], row j % page_block_size.
+     * page_block_size must be a multiple of 256 (so that no 64-key tile straddles two pages).  NULL = contiguous. */
+    const int32_t *block_table;
+    int64_t block_table_batch_stride;
+    int32_t page_block_size;
+    int32_t reserved0;
 } fa_fwd_params;
 
 /* Validate and enqueue the forward on `stream` (a hipStream_t; NULL = default
@@ -183,6 +192,11 @@ typedef struct fa_kvcache_append_params {
     int32_t reserved;
     const int32_t *cache_seqlens;   /* (b) int32, rows already valid in each cache entry */
     const int32_t *cache_batch_idx; /* (b) int32 or NULL */
+    const int32_t *block_table;     /* paged cache (see fa_fwd_params) or NULL; then seqlen_cache = pages per sequence
+                                       x page_block_size and k/vcache_batch_stride is the page stride */
+    int64_t block_table_batch_stride;
+    int32_t page_block_size;
+    int32_t reserved1;
 } fa_kvcache_append_params;
 
 int fa_kvcache_append(const fa_kvcache_append_params *params, void *stream);

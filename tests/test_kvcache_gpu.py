@@ -95,9 +95,76 @@ def test_kvcache_rejects_unbuilt_features_by_message():
     fa = _api()
     q = torch.randn(1, 1, 2, 64, dtype=torch.bfloat16, device=DEV)
     kc = torch.randn(1, 256, 2, 64, dtype=torch.bfloat16, device=DEV)
-    with pytest.raises(RuntimeError, match="paged KV"):
-        fa.flash_attn_with_kvcache(q, kc, kc, block_table=torch.zeros(1, 1, dtype=torch.int32, device=DEV))
+    with pytest.raises(RuntimeError, match="divisible by 256"):
+        fa.flash_attn_with_kvcache(q, kc[:, :100], kc[:, :100], block_table=torch.zeros(1, 1, dtype=torch.int32, device=DEV))
     with pytest.raises(RuntimeError, match="rotary"):
         fa.flash_attn_with_kvcache(q, kc, kc, rotary_cos=torch.zeros(256, 16, device=DEV), rotary_sin=torch.zeros(256, 16, device=DEV))
     with pytest.raises(RuntimeError, match="seqlens_k must also be passed in"):
         fa.flash_attn_with_kvcache(q, kc, kc, k=q[:, :, :2], v=q[:, :, :2])
+
+
+def _paged(k_cache, v_cache, page, seed):
+    """Scatter contiguous (b, sk, h_k, d) caches into a shuffled page pool, as tests/test_flash_attn.py:1975-1992 does."""
+    b, sk = k_cache.shape[:2]
+    nblk = sk // page
+    g = torch.Generator().manual_seed(seed)
+    num_blocks = b * nblk * 3
+    table = torch.randperm(num_blocks, generator=g, dtype=torch.int32)[: b * nblk].view(b, nblk)
+    kp = torch.randn(num_blocks, page, *k_cache.shape[2:], generator=g).to(k_cache.dtype)
+    vp = torch.randn(num_blocks, page, *v_cache.shape[2:], generator=g).to(v_cache.dtype)
+    kp[table.flatten().long()] = k_cache.reshape(b * nblk, page, *k_cache.shape[2:])
+    vp[table.flatten().long()] = v_cache.reshape(b * nblk, page, *v_cache.shape[2:])
+    return kp, vp, table
+
+
+@pytest.mark.parametrize("new_kv", [False, True])
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("sq,sk,d,page", [(1, 1024, 128, 256), (1, 2048, 64, 512), (5, 768, 128, 256), (70, 512, 256, 256)])
+def test_kvcache_paged(sq, sk, d, page, causal, new_kv):
+    """Paged cache (block_table): same expectation as the contiguous cache it was scattered from; appended rows land
+    in the right pages and nothing else in the pool changes."""
+    fa = _api()
+    torch.manual_seed(sq + sk + d)
+    b, h, hk = 3, 4, 2
+    sk_new = sq if new_kv else 0
+    q = torch.randn(b, sq, h, d, dtype=torch.bfloat16)
+    k_cache = torch.randn(b, sk, hk, d, dtype=torch.bfloat16)
+    v_cache = torch.randn(b, sk, hk, d, dtype=torch.bfloat16)
+    k = torch.randn(b, sk_new, hk, d, dtype=torch.bfloat16) if new_kv else None
+    v = torch.randn(b, sk_new, hk, d, dtype=torch.bfloat16) if new_kv else None
+    cache_seqlens = torch.randint(0 if new_kv else 1, sk - sk_new + 1, (b,), dtype=torch.int32)
+    out_ref, out_pt, lse_ref, kc_ref, vc_ref, _ = _expected(q, k_cache, v_cache, k, v, cache_seqlens, None, causal=causal)
+    kp, vp, table = _paged(k_cache, v_cache, page, seed=d)
+    kp_d, vp_d = kp.to(DEV), vp.to(DEV)
+    out = fa.flash_attn_with_kvcache(q.to(DEV), kp_d, vp_d, None if k is None else k.to(DEV),
+                                     None if v is None else v.to(DEV), cache_seqlens=cache_seqlens.to(DEV),
+                                     block_table=table.to(DEV), causal=causal)
+    err = (out.float().cpu() - out_ref.float()).abs().max().item()
+    bound = 3 * (out_pt.float() - out_ref.float()).abs().max().item() + 1e-5
+    assert err <= bound, f"out err {err:.3e} > {bound:.3e}"
+    kp_want, vp_want, _ = _paged(kc_ref, vc_ref, page, seed=d)  # same pool, same table, with the appended rows
+    assert torch.equal(kp_d.cpu(), kp_want) and torch.equal(vp_d.cpu(), vp_want)
+
+
+def test_varlen_paged_kv():
+    """flash_attn_varlen_func(..., block_table=...) (csrc/flash_attn/flash_api.cpp:554-560, 608-612): k, v are a page
+    pool, cu_seqlens_k gives the lengths."""
+    fa = _api()
+    torch.manual_seed(9)
+    b, h, hk, d, page, sk = 3, 4, 2, 128, 256, 768
+    lens_q, lens_k = [40, 1, 130], [700, 256, 300]
+    k_cache = torch.randn(b, sk, hk, d, dtype=torch.float16)
+    v_cache = torch.randn(b, sk, hk, d, dtype=torch.float16)
+    kp, vp, table = _paged(k_cache, v_cache, page, seed=1)
+    q = torch.randn(sum(lens_q), h, d, dtype=torch.float16)
+    cuq = torch.tensor([0, 40, 41, 171], dtype=torch.int32)
+    cuk = torch.tensor([0, 700, 956, 1256], dtype=torch.int32)
+    out = fa.flash_attn_varlen_func(q.to(DEV), kp.to(DEV), vp.to(DEV), cuq.to(DEV), cuk.to(DEV), max(lens_q), sk,
+                                    causal=True, block_table=table.to(DEV))
+    for i in range(b):
+        qs = slice(cuq[i], cuq[i + 1])
+        ref, _ = oracle.attention_ref(q[qs][None], k_cache[i:i + 1, :lens_k[i]], v_cache[i:i + 1, :lens_k[i]], causal=True)
+        pt, _ = oracle.attention_ref(q[qs][None], k_cache[i:i + 1, :lens_k[i]], v_cache[i:i + 1, :lens_k[i]], causal=True,
+                                     upcast=False, reorder_ops=True)
+        err = (out[qs].float().cpu() - ref[0].float()).abs().max().item()
+        assert err <= 2 * (pt.float() - ref.float()).abs().max().item() + 1e-5, (i, err)
