@@ -133,7 +133,31 @@ def launch_bwd(dout, q, k, v, out, lse, dq, dk, dv, softmax_d, *, varlen, batch,
         raise RuntimeError(f"fa_bwd failed ({st}): {_lib.strerror(st)}")
 
 
-def kvcache_append(k_new, v_new, k_cache, v_cache, cache_seqlens, cache_batch_idx=None, block_table=None):
+def rotary_apply(src, dst, cos, sin, seqlen_offsets, interleaved, per_row_positions):
+    """dst[b, i] = rotary(src[b, i]) at position seqlen_offsets[b] + (i if per_row_positions else 0); (b, s, h, d)."""
+    lib = _lib.load()
+    prm = _lib.FaRotaryParams()
+    prm.abi_version = _lib.FA_ABI_VERSION
+    prm.struct_size = ctypes.sizeof(_lib.FaRotaryParams)
+    prm.src, prm.dst = ptr(src), ptr(dst)
+    for name, t in (("src", src), ("dst", dst)):
+        setattr(prm, f"{name}_batch_stride", t.stride(0))
+        setattr(prm, f"{name}_row_stride", t.stride(1))
+        setattr(prm, f"{name}_head_stride", t.stride(2))
+    prm.b, prm.s, prm.h, prm.d = src.shape
+    prm.dtype = _DT[src.dtype]
+    prm.rotary_dim = cos.shape[1] * 2
+    prm.rotary_interleaved = int(bool(interleaved))
+    prm.per_row_positions = int(bool(per_row_positions))
+    prm.rotary_cos, prm.rotary_sin, prm.seqlen_offsets = ptr(cos), ptr(sin), ptr(seqlen_offsets)
+    stream = torch.cuda.current_stream(src.device).cuda_stream
+    st = lib.fa_rotary_apply(ctypes.byref(prm), ctypes.c_void_p(stream))
+    if st != 0:
+        raise RuntimeError(f"fa_rotary_apply failed ({st}): {_lib.strerror(st)}")
+
+
+def kvcache_append(k_new, v_new, k_cache, v_cache, cache_seqlens, cache_batch_idx=None, block_table=None,
+                   rotary_cos=None, rotary_sin=None, rotary_interleaved=False):
     """(b, s_new, h_k, d) rows appended in place to (b_cache, s_cache, h_k, d) caches at cache_seqlens (int32, (b,))."""
     lib = _lib.load()
     prm = _lib.FaKvcacheAppendParams()
@@ -153,6 +177,11 @@ def kvcache_append(k_new, v_new, k_cache, v_cache, cache_seqlens, cache_batch_id
         prm.seqlen_cache = block_table.shape[1] * k_cache.shape[1]
     prm.cache_seqlens = ptr(cache_seqlens)
     prm.cache_batch_idx = ptr(cache_batch_idx)
+    prm.dtype = _DT[k_new.dtype]
+    if rotary_cos is not None:
+        prm.rotary_cos, prm.rotary_sin = ptr(rotary_cos), ptr(rotary_sin)
+        prm.rotary_dim = rotary_cos.shape[1] * 2
+        prm.rotary_interleaved = int(bool(rotary_interleaved))
     stream = torch.cuda.current_stream(k_new.device).cuda_stream
     st = lib.fa_kvcache_append(ctypes.byref(prm), ctypes.c_void_p(stream))
     if st != 0:

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, LIB_NAME)
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
-FA_ABI_VERSION = 5
+FA_ABI_VERSION = 6
 FA_DTYPE_FP16, FA_DTYPE_BF16, FA_DTYPE_FP8_E4M3 = 0, 1, 2
 
 # every symbol include/fa_fwd.h declares (tests check the .so exports all of them)
@@ -29,6 +29,8 @@ EXPORTED_SYMBOLS = (
     "fa_set_default_variant",
     "fa_kvcache_append",
     "fa_kvcache_append_params_size",
+    "fa_rotary_apply",
+    "fa_rotary_params_size",
     # include/fa_bwd.h
     "fa_bwd",
     "fa_bwd_validate",
@@ -110,7 +112,20 @@ class FaKvcacheAppendParams(ctypes.Structure):
         + [(n, ctypes.c_int32) for n in ("b", "seqlen_new", "seqlen_cache", "h_k", "d", "reserved")]
         + [("cache_seqlens", ctypes.c_void_p), ("cache_batch_idx", ctypes.c_void_p)]
         + [("block_table", ctypes.c_void_p), ("block_table_batch_stride", ctypes.c_int64),
-           ("page_block_size", ctypes.c_int32), ("reserved1", ctypes.c_int32)]
+           ("page_block_size", ctypes.c_int32), ("dtype", ctypes.c_int32)]
+        + [("rotary_cos", ctypes.c_void_p), ("rotary_sin", ctypes.c_void_p),
+           ("rotary_dim", ctypes.c_int32), ("rotary_interleaved", ctypes.c_int32)]
+    )
+
+
+class FaRotaryParams(ctypes.Structure):
+    """Field-for-field mirror of `struct fa_rotary_params` (include/fa_fwd.h)."""
+
+    _fields_ = (
+        [("abi_version", ctypes.c_uint32), ("struct_size", ctypes.c_uint32), ("src", ctypes.c_void_p), ("dst", ctypes.c_void_p)]
+        + [(f"{t}_{s}_stride", ctypes.c_int64) for t in ("src", "dst") for s in ("batch", "row", "head")]
+        + [(n, ctypes.c_int32) for n in ("b", "s", "h", "d", "dtype", "rotary_dim", "rotary_interleaved", "per_row_positions")]
+        + [("rotary_cos", ctypes.c_void_p), ("rotary_sin", ctypes.c_void_p), ("seqlen_offsets", ctypes.c_void_p)]
     )
 
 
@@ -188,6 +203,12 @@ def load():
     lib.fa_kvcache_append_params_size.restype = ctypes.c_uint32
     if lib.fa_kvcache_append_params_size() != ctypes.sizeof(FaKvcacheAppendParams):
         raise RuntimeError("fa_kvcache_append_params layout mismatch between include/fa_fwd.h and _lib")
+    lib.fa_rotary_apply.argtypes = [ctypes.POINTER(FaRotaryParams), ctypes.c_void_p]
+    lib.fa_rotary_apply.restype = ctypes.c_int
+    lib.fa_rotary_params_size.argtypes = []
+    lib.fa_rotary_params_size.restype = ctypes.c_uint32
+    if lib.fa_rotary_params_size() != ctypes.sizeof(FaRotaryParams):
+        raise RuntimeError("fa_rotary_params layout mismatch between include/fa_fwd.h and _lib")
     lib.fa_bwd.argtypes = [ctypes.POINTER(FaBwdParams), ctypes.c_void_p]
     lib.fa_bwd.restype = ctypes.c_int
     lib.fa_bwd_validate.argtypes = [ctypes.POINTER(FaBwdParams)]

@@ -47,31 +47,138 @@ __global__ void expand_fp8_kernel(const uint8_t *__restrict__ src, uint32_t *__r
     }
 }
 
-// ---- KV-cache append: k_new/v_new rows -> cache rows [cache_seqlens[b], +seqlen_new).  One thread = one 16-byte chunk
-// of K and the same chunk of V.  HBM-bound elementwise pass.
-__global__ void kvcache_append_kernel(const fa_kvcache_append_params p) {
-    const int chunks = p.d >> 3;
-    const int64_t total = (int64_t)p.b * p.seqlen_new * p.h_k * chunks;
+// ---- rotary embedding on 16-byte chunks (8 elements), fp32 math, round to the storage type -------------------------
+template <typename T>
+__device__ __forceinline__ void unpack8(const uint4 &w, float (&x)[8]) {
+    const uint32_t u[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if constexpr (sizeof(T) == 2 && __is_same(T, __bf16)) {
+            x[2 * j] = __uint_as_float(u[j] << 16);
+            x[2 * j + 1] = __uint_as_float(u[j] & 0xffff0000u);
+        } else {
+            x[2 * j] = (float)__builtin_bit_cast(_Float16, (uint16_t)(u[j] & 0xffffu));
+            x[2 * j + 1] = (float)__builtin_bit_cast(_Float16, (uint16_t)(u[j] >> 16));
+        }
+    }
+}
+template <typename T>
+__device__ __forceinline__ uint4 pack8(const float (&x)[8]) {
+    uint32_t u[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) u[j] = fa::Elem<T>::pack2(x[2 * j], x[2 * j + 1]);
+    return make_uint4(u[0], u[1], u[2], u[3]);
+}
+// One work item = one pair of chunks.  Interleaved: chunk c holds pairs (2j, 2j+1): rotated in place with cos/sin
+// [4c, 4c+4).  Otherwise chunk c (< rotary_dim/16) pairs with chunk c + rotary_dim/16, cos/sin [8c, 8c+8).
+// Chunks past rotary_dim are copied.  `item` enumerates ceil(d/16) slots per (row, head): slot j covers chunk j (first
+// half of the rotary part), its partner, and -- past the rotary part -- the plain chunks 2 per slot.
+template <typename T>
+__device__ __forceinline__ void rotary_slot(const T *src, T *dst, int d, int rd, bool interleaved, int slot,
+                                            const T *cos_row, const T *sin_row) {
+    const int chunks = d >> 3, rchunks = rd >> 3;
+    int c0, c1;  // the two chunks of this slot (c1 = -1: none)
+    if (slot < rchunks / 2 + (rchunks & 1)) {
+        if (interleaved) { c0 = 2 * slot; c1 = 2 * slot + 1 < rchunks ? 2 * slot + 1 : -1; }
+        else { c0 = slot; c1 = slot + rchunks / 2; }
+    } else {  // plain chunks behind the rotary part, two per slot
+        const int k = slot - (rchunks / 2 + (rchunks & 1));
+        c0 = rchunks + 2 * k;
+        c1 = c0 + 1 < chunks ? c0 + 1 : -1;
+        if (c0 >= chunks) return;
+        *reinterpret_cast<uint4 *>(dst + c0 * 8) = *reinterpret_cast<const uint4 *>(src + c0 * 8);
+        if (c1 >= 0) *reinterpret_cast<uint4 *>(dst + c1 * 8) = *reinterpret_cast<const uint4 *>(src + c1 * 8);
+        return;
+    }
+    if (interleaved) {
+        const int cs[2] = {c0, c1};
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int c = cs[q];
+            if (c < 0) continue;
+            float x[8], cv[8], sv[8], y[8];
+            unpack8<T>(*reinterpret_cast<const uint4 *>(src + c * 8), x);
+            // 4 cos/sin values for this chunk: load the aligned 8 and pick the half
+            unpack8<T>(*reinterpret_cast<const uint4 *>(cos_row + (c >> 1) * 8), cv);
+            unpack8<T>(*reinterpret_cast<const uint4 *>(sin_row + (c >> 1) * 8), sv);
+            const int h = (c & 1) * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float co = cv[h + j], si = sv[h + j];
+                y[2 * j] = x[2 * j] * co - x[2 * j + 1] * si;
+                y[2 * j + 1] = x[2 * j + 1] * co + x[2 * j] * si;
+            }
+            *reinterpret_cast<uint4 *>(dst + c * 8) = pack8<T>(y);
+        }
+    } else {
+        float x1[8], x2[8], cv[8], sv[8], y1[8], y2[8];
+        unpack8<T>(*reinterpret_cast<const uint4 *>(src + c0 * 8), x1);
+        unpack8<T>(*reinterpret_cast<const uint4 *>(src + c1 * 8), x2);
+        unpack8<T>(*reinterpret_cast<const uint4 *>(cos_row + c0 * 8), cv);
+        unpack8<T>(*reinterpret_cast<const uint4 *>(sin_row + c0 * 8), sv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            y1[j] = x1[j] * cv[j] - x2[j] * sv[j];
+            y2[j] = x2[j] * cv[j] + x1[j] * sv[j];
+        }
+        *reinterpret_cast<uint4 *>(dst + c0 * 8) = pack8<T>(y1);
+        *reinterpret_cast<uint4 *>(dst + c1 * 8) = pack8<T>(y2);
+    }
+}
+
+template <typename T>
+__global__ void rotary_kernel(const fa_rotary_params p) {
+    const int slots = (p.d / 8 + 1) / 2;
+    const int64_t total = (int64_t)p.b * p.s * p.h * slots;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % chunks);
-        int64_t t = i / chunks;
+        const int slot = (int)(i % slots);
+        int64_t t = i / slots;
+        const int hd = (int)(t % p.h);
+        t /= p.h;
+        const int row = (int)(t % p.s);
+        const int b = (int)(t / p.s);
+        const int pos = p.seqlen_offsets[b] + (p.per_row_positions ? row : 0);
+        const T *src = (const T *)p.src + b * p.src_batch_stride + row * p.src_row_stride + hd * p.src_head_stride;
+        T *dst = (T *)p.dst + b * p.dst_batch_stride + row * p.dst_row_stride + hd * p.dst_head_stride;
+        const T *cr = (const T *)p.rotary_cos + (int64_t)pos * (p.rotary_dim / 2);
+        const T *sr = (const T *)p.rotary_sin + (int64_t)pos * (p.rotary_dim / 2);
+        rotary_slot<T>(src, dst, p.d, p.rotary_dim, p.rotary_interleaved != 0, slot, cr, sr);
+    }
+}
+
+// ---- KV-cache append: k_new/v_new rows -> cache rows [cache_seqlens[b], +seqlen_new), keys optionally rotated.
+// One thread = one slot of two 16-byte chunks of K and the same chunks of V.  HBM-bound elementwise pass.
+template <typename T>
+__global__ void kvcache_append_kernel(const fa_kvcache_append_params p) {
+    const int slots = (p.d / 8 + 1) / 2, chunks = p.d >> 3;
+    const int64_t total = (int64_t)p.b * p.seqlen_new * p.h_k * slots;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int slot = (int)(i % slots);
+        int64_t t = i / slots;
         const int hd = (int)(t % p.h_k);
         t /= p.h_k;
         const int row = (int)(t % p.seqlen_new);
         const int b = (int)(t / p.seqlen_new);
         int dst_row = p.cache_seqlens[b] + row;
         if (dst_row < 0 || dst_row >= p.seqlen_cache) continue;
+        const int pos = dst_row;
         int cb = p.cache_batch_idx ? p.cache_batch_idx[b] : b;
         if (p.block_table) {
             cb = p.block_table[b * p.block_table_batch_stride + dst_row / p.page_block_size];
             dst_row %= p.page_block_size;
         }
-        const uint16_t *ks = (const uint16_t *)p.k_new + b * p.knew_batch_stride + row * p.knew_row_stride + hd * p.knew_head_stride + c * 8;
-        const uint16_t *vs = (const uint16_t *)p.v_new + b * p.vnew_batch_stride + row * p.vnew_row_stride + hd * p.vnew_head_stride + c * 8;
-        uint16_t *kd = (uint16_t *)p.k_cache + cb * p.kcache_batch_stride + dst_row * p.kcache_row_stride + hd * p.kcache_head_stride + c * 8;
-        uint16_t *vd = (uint16_t *)p.v_cache + cb * p.vcache_batch_stride + dst_row * p.vcache_row_stride + hd * p.vcache_head_stride + c * 8;
-        *reinterpret_cast<uint4 *>(kd) = *reinterpret_cast<const uint4 *>(ks);
-        *reinterpret_cast<uint4 *>(vd) = *reinterpret_cast<const uint4 *>(vs);
+        const T *ks = (const T *)p.k_new + b * p.knew_batch_stride + row * p.knew_row_stride + hd * p.knew_head_stride;
+        const T *vs = (const T *)p.v_new + b * p.vnew_batch_stride + row * p.vnew_row_stride + hd * p.vnew_head_stride;
+        T *kd = (T *)p.k_cache + cb * p.kcache_batch_stride + dst_row * p.kcache_row_stride + hd * p.kcache_head_stride;
+        T *vd = (T *)p.v_cache + cb * p.vcache_batch_stride + dst_row * p.vcache_row_stride + hd * p.vcache_head_stride;
+        const int rd = p.rotary_cos ? p.rotary_dim : 0;
+        const T *cr = (const T *)p.rotary_cos + (int64_t)pos * (rd / 2);
+        const T *sr = (const T *)p.rotary_sin + (int64_t)pos * (rd / 2);
+        rotary_slot<T>(ks, kd, p.d, rd, p.rotary_interleaved != 0, slot, cr, sr);
+        // V: the same enumeration without a rotary part (slot -> chunks 2 slot, 2 slot + 1)
+        const int c0 = 2 * slot, c1 = 2 * slot + 1;
+        if (c0 < chunks) *reinterpret_cast<uint4 *>(vd + c0 * 8) = *reinterpret_cast<const uint4 *>(vs + c0 * 8);
+        if (c1 < chunks) *reinterpret_cast<uint4 *>(vd + c1 * 8) = *reinterpret_cast<const uint4 *>(vs + c1 * 8);
     }
 }
 
@@ -210,6 +317,13 @@ int fa_kvcache_append(const fa_kvcache_append_params *p, void *stream_) {
     if (p->seqlen_new == 0) return FA_OK;
     if (!p->k_new || !p->v_new || !p->k_cache || !p->v_cache || !p->cache_seqlens) return FA_ERR_NULL_POINTER;
     if (p->block_table && (p->page_block_size <= 0 || p->cache_batch_idx)) return FA_ERR_BAD_SHAPE;
+    if (p->rotary_cos) {
+        if (!p->rotary_sin) return FA_ERR_NULL_POINTER;
+        if (p->dtype != FA_DTYPE_FP16 && p->dtype != FA_DTYPE_BF16) return FA_ERR_BAD_DTYPE;
+        if (p->rotary_dim <= 0 || p->rotary_dim > p->d || p->rotary_dim % 16 != 0) return FA_ERR_BAD_SHAPE;  // (:1409-1410)
+        if (reinterpret_cast<uintptr_t>(p->rotary_cos) % 16 != 0 || reinterpret_cast<uintptr_t>(p->rotary_sin) % 16 != 0)
+            return FA_ERR_BAD_STRIDE;
+    }
     const int64_t strides[] = {p->knew_batch_stride, p->knew_row_stride, p->knew_head_stride, p->vnew_batch_stride,
                                p->vnew_row_stride, p->vnew_head_stride, p->kcache_batch_stride, p->kcache_row_stride,
                                p->kcache_head_stride, p->vcache_batch_stride, p->vcache_row_stride, p->vcache_head_stride};
@@ -218,9 +332,40 @@ int fa_kvcache_append(const fa_kvcache_append_params *p, void *stream_) {
     const void *ptrs[] = {p->k_new, p->v_new, p->k_cache, p->v_cache};
     for (const void *ptr : ptrs)
         if (reinterpret_cast<uintptr_t>(ptr) % 16 != 0) return FA_ERR_BAD_STRIDE;
-    const int64_t total = (int64_t)p->b * p->seqlen_new * p->h_k * (p->d / 8);
+    const int64_t total = (int64_t)p->b * p->seqlen_new * p->h_k * ((p->d / 8 + 1) / 2);
     const int blocks = (int)std::min<int64_t>((total + 255) / 256, 256 * 8);
-    hipLaunchKernelGGL(kvcache_append_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream_), *p);
+    if (p->rotary_cos && p->dtype == FA_DTYPE_FP16)
+        hipLaunchKernelGGL(kvcache_append_kernel<_Float16>, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream_), *p);
+    else  // (without rotary the element type does not matter: plain 16-byte copies)
+        hipLaunchKernelGGL(kvcache_append_kernel<__bf16>, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream_), *p);
+    if (hipGetLastError() != hipSuccess) return FA_ERR_LAUNCH;
+    return FA_OK;
+}
+
+uint32_t fa_rotary_params_size(void) { return (uint32_t)sizeof(fa_rotary_params); }
+
+int fa_rotary_apply(const fa_rotary_params *p, void *stream_) {
+    if (!p) return FA_ERR_NULL_POINTER;
+    if (p->abi_version != FA_ABI_VERSION || p->struct_size != sizeof(fa_rotary_params)) return FA_ERR_BAD_ABI;
+    if (p->dtype != FA_DTYPE_FP16 && p->dtype != FA_DTYPE_BF16) return FA_ERR_BAD_DTYPE;
+    if (p->b <= 0 || p->h <= 0 || p->s < 0) return FA_ERR_BAD_SHAPE;
+    if (p->d <= 0 || p->d > 256 || p->d % 8 != 0) return FA_ERR_BAD_HEAD_DIM;
+    if (p->rotary_dim <= 0 || p->rotary_dim > p->d || p->rotary_dim % 16 != 0) return FA_ERR_BAD_SHAPE;
+    if (p->s == 0) return FA_OK;
+    if (!p->src || !p->dst || !p->rotary_cos || !p->rotary_sin || !p->seqlen_offsets) return FA_ERR_NULL_POINTER;
+    const int64_t strides[] = {p->src_batch_stride, p->src_row_stride, p->src_head_stride, p->dst_batch_stride,
+                               p->dst_row_stride, p->dst_head_stride};
+    for (int64_t s : strides)
+        if (s % 8 != 0) return FA_ERR_BAD_STRIDE;
+    const void *ptrs[] = {p->src, p->dst, p->rotary_cos, p->rotary_sin};
+    for (const void *ptr : ptrs)
+        if (reinterpret_cast<uintptr_t>(ptr) % 16 != 0) return FA_ERR_BAD_STRIDE;
+    const int64_t total = (int64_t)p->b * p->s * p->h * ((p->d / 8 + 1) / 2);
+    const int blocks = (int)std::min<int64_t>((total + 255) / 256, 256 * 8);
+    if (p->dtype == FA_DTYPE_FP16)
+        hipLaunchKernelGGL(rotary_kernel<_Float16>, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream_), *p);
+    else
+        hipLaunchKernelGGL(rotary_kernel<__bf16>, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream_), *p);
     if (hipGetLastError() != hipSuccess) return FA_ERR_LAUNCH;
     return FA_OK;
 }

@@ -402,7 +402,6 @@ def fwd_kvcache(q: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor, k_:
     if paged:
         _check(cache_batch_idx_ is None, "Paged KVcache does not support cache_batch_idx")
     _check(leftpad_k_ is None, "This flash attention build does not support leftpad_k.")
-    _check(rotary_cos_ is None and rotary_sin_ is None, "This flash attention build does not support rotary embedding in fwd_kvcache.")
 
     batch_size, seqlen_q, num_heads, head_size_og = q.shape
     batch_size_c, seqlen_k, num_heads_k = kcache.shape[0], kcache.shape[1], kcache.shape[2]
@@ -470,15 +469,40 @@ def fwd_kvcache(q: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor, k_:
         _check(batch_size_c >= batch_size, "the KV cache must have at least batch_size entries")
     for t in (kcache, vcache):
         _check(_aligned(t), "the KV cache must be 16-byte aligned with row/head/batch strides that are multiples of 8")
+    rotary = rotary_cos_ is not None
+    if rotary:  # (:1404-1428)
+        _check(k_ is not None, "If rotary cos/sin are provided, new key / value to be appended to KV cache must also be provided")
+        _check_device(rotary_cos_, "rotary_cos")
+        rotary_dim = rotary_cos_.shape[1] * 2
+        _check(rotary_dim <= head_size_og, "rotary_dim must be <= headdim")
+        _check(rotary_dim % 16 == 0, "Only rotary dimensions divisible by 16 are currently supported")
+        seqlen_ro = rotary_cos_.shape[0]
+        _check(seqlen_ro >= seqlen_k, "cos/sin seqlen must be at least the seqlen of KV cache")
+        _check_shape(rotary_cos_, "rotary_cos", seqlen_ro, rotary_dim // 2)
+        _check(rotary_cos_.is_contiguous(), "rotary_cos must be contiguous")
+        _check(rotary_cos_.dtype == q_dtype, "rotary_cos must have the same dtype as query")
+        _check(rotary_sin_ is not None, "If rotary cos is provided, rotary sin must also be provided")
+        _check_device(rotary_sin_, "rotary_sin")
+        _check_shape(rotary_sin_, "rotary_sin", seqlen_ro, rotary_dim // 2)
+        _check(rotary_sin_.is_contiguous(), "rotary_sin must be contiguous")
+        _check(rotary_sin_.dtype == q_dtype, "rotary_cos must have the same dtype as query")
 
     with torch.cuda.device(q.device):
         softmax_lse = torch.empty((batch_size, num_heads, seqlen_q), dtype=torch.float32, device=q.device)
         seqused = seqlens_k_
         if seqlen_knew > 0:  # "Append_KV": new rows land at [seqlens_k, seqlens_k + seqlen_knew) of each cache entry
             kn, vn = (x if _aligned(x) else x.contiguous() for x in (k_, v_))
-            _dispatch.kvcache_append(kn, vn, kcache, vcache, seqlens_k_, cache_batch_idx_, block_table_)
+            _dispatch.kvcache_append(kn, vn, kcache, vcache, seqlens_k_, cache_batch_idx_, block_table_,
+                                     rotary_cos_, rotary_sin_, is_rotary_interleaved)
             seqused = seqlens_k_ + seqlen_knew
         qc = q if _aligned(q) else q.contiguous()
+        if rotary:
+            # causal / local: query row i sits at position seqlens_k + i; otherwise every row at seqlens_k
+            # (flash_attn/flash_attn_interface.py:1516-1524, src/flash_fwd_kernel.h:753-775)
+            per_row = is_causal or window_size_left >= 0 or window_size_right >= 0
+            q_ro = torch.empty_like(qc, memory_format=torch.contiguous_format)
+            _dispatch.rotary_apply(qc, q_ro, rotary_cos_, rotary_sin_, seqlens_k_, is_rotary_interleaved, per_row)
+            qc = q_ro
         oc = out if _aligned(out) else torch.empty_like(out, memory_format=torch.contiguous_format)
         if seqlen_k > 0:
             _dispatch.launch(qc, kcache, vcache, oc, softmax_lse, varlen=False, batch=batch_size,

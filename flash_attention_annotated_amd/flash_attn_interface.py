@@ -323,7 +323,10 @@ def flash_attn_with_kvcache(q, k_cache, v_cache, k=None, v=None, rotary_cos=None
     Causal / window masks are aligned to the bottom-right corner of each (seqlen_q, cache_seqlens + seqlen_new) block.
     block_table: (batch, max_blocks_per_seq) int32 for a paged cache (k_cache, v_cache: (num_blocks, page_block_size,
     nheads_k, headdim), page_block_size % 256 == 0).
-    Not built (rejected by message): rotary_cos/sin, cache_leftpad; num_splits is ignored.
+    rotary_cos / rotary_sin: (seqlen_ro, rotary_dim / 2): rotary embedding of the appended keys (position
+    cache_seqlens + i) and of q (the same positions when causal / local, otherwise all rows at cache_seqlens);
+    rotary_interleaved: pairs (2j, 2j+1) instead of (j, j + rotary_dim/2).
+    Not built (rejected by message): cache_leftpad; num_splits is ignored.
     Returns out (batch, seqlen_q, nheads, headdim) [, softmax_lse (batch, nheads, seqlen_q)]."""
     assert k_cache.stride(-1) == 1, "k_cache must have contiguous last dimension"
     assert v_cache.stride(-1) == 1, "v_cache must have contiguous last dimension"

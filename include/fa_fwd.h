@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define FA_ABI_VERSION 5
+#define FA_ABI_VERSION 6
 
 /* element types of q/k/v (o has the same type; fp8 inputs produce bf16 o) */
 enum fa_dtype {
@@ -196,11 +196,44 @@ typedef struct fa_kvcache_append_params {
                                        x page_block_size and k/vcache_batch_stride is the page stride */
     int64_t block_table_batch_stride;
     int32_t page_block_size;
-    int32_t reserved1;
+    int32_t dtype; /* enum fa_dtype (16-bit types); only read when rotary_cos is set */
+    /* Rotary embedding of the appended KEYS (csrc/flash_attn/flash_api.cpp:1404-1428, src/flash_fwd_kernel.h:679-735):
+     * row i of k_new is rotated by position cache_seqlens[b] + i before it is stored; values are copied unchanged.
+     * rotary_cos / rotary_sin: (seqlen_ro, rotary_dim / 2), contiguous, same 16-bit dtype as k; rotary_dim % 16 == 0,
+     * <= d; interleaved: pairs (2j, 2j+1) (GPT-J), otherwise (j, j + rotary_dim/2) (GPT-NeoX).  NULL = no rotary. */
+    const void *rotary_cos;
+    const void *rotary_sin;
+    int32_t rotary_dim;
+    int32_t rotary_interleaved;
 } fa_kvcache_append_params;
 
 int fa_kvcache_append(const fa_kvcache_append_params *params, void *stream);
 uint32_t fa_kvcache_append_params_size(void);
+
+/*
+ * Rotary embedding of a (b, s, h, d) tensor into `dst` (same shape; dst may alias src): row i of batch b is rotated by
+ * position seqlen_offsets[b] + (per_row_positions ? i : 0) -- the query side of mha_fwd_kvcache (causal / local: one
+ * position per query row; otherwise every row at cache_seqlens, flash_attn/flash_attn_interface.py:1516-1524).
+ */
+typedef struct fa_rotary_params {
+    uint32_t abi_version;
+    uint32_t struct_size;
+    const void *src;
+    void *dst;
+    int64_t src_batch_stride, src_row_stride, src_head_stride;
+    int64_t dst_batch_stride, dst_row_stride, dst_head_stride;
+    int32_t b, s, h, d;
+    int32_t dtype; /* FA_DTYPE_FP16 / FA_DTYPE_BF16 */
+    int32_t rotary_dim;
+    int32_t rotary_interleaved;
+    int32_t per_row_positions;
+    const void *rotary_cos; /* (seqlen_ro, rotary_dim / 2) */
+    const void *rotary_sin;
+    const int32_t *seqlen_offsets; /* (b) */
+} fa_rotary_params;
+
+int fa_rotary_apply(const fa_rotary_params *params, void *stream);
+uint32_t fa_rotary_params_size(void);
 
 /* Test hook: overrides the default kernel variant process-wide (0 = default). */
 void fa_set_default_variant(int32_t variant);

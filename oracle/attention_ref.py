@@ -51,6 +51,31 @@ def attn_bias_from_alibi_slopes(slopes, seqlen_q, seqlen_k, query_padding_mask=N
     return -sl * torch.abs(i + sk - sq - j).to(slopes.dtype)
 
 
+def apply_rotary_emb_ref(x, cos, sin, seqlen_offsets, interleaved=False, per_row_positions=True):
+    """Rotary embedding of x (b, s, h, d) with per-batch position offsets: restates apply_rotary_emb_torch
+    (flash_attn/layers/rotary.py:14-36) called the way tests/test_flash_attn.py:2017-2036 calls apply_rotary_emb
+    (seqlen_offsets = cache_seqlens; the non-causal query case folds s into the head dim, i.e. one position).
+    cos, sin: (seqlen_ro, rotary_dim / 2).  Math in fp32, result in x.dtype."""
+    b, s, h, d = x.shape
+    rd = cos.shape[-1] * 2
+    pos = seqlen_offsets.long().view(b, 1) + (torch.arange(s).view(1, s) if per_row_positions else 0)
+    pos = pos.expand(b, s)
+    c, sn = cos.float()[pos], sin.float()[pos]  # (b, s, rd/2)
+    if interleaved:
+        c, sn = c.repeat_interleave(2, dim=-1), sn.repeat_interleave(2, dim=-1)
+    else:
+        c, sn = torch.cat([c, c], dim=-1), torch.cat([sn, sn], dim=-1)
+    xr = x[..., :rd].float()
+    if interleaved:
+        x1, x2 = xr[..., ::2], xr[..., 1::2]
+        rot = torch.stack((-x2, x1), dim=-1).flatten(-2)
+    else:
+        x1, x2 = xr.chunk(2, dim=-1)
+        rot = torch.cat((-x2, x1), dim=-1)
+    out = xr * c[:, :, None, :] + rot * sn[:, :, None, :]
+    return torch.cat([out.to(x.dtype), x[..., rd:]], dim=-1)
+
+
 def attention_ref(q, k, v, query_padding_mask=None, key_padding_mask=None, attn_bias=None, causal=False,
                   window_size=(-1, -1), softcap=0.0, upcast=True, reorder_ops=False, return_lse=False,
                   q_descale=None, k_descale=None, v_descale=None, intermediate_dtype=None):

@@ -159,6 +159,22 @@ def main():
     torch.save(golden, out_path)
     print(f"wrote {out_path} ({os.path.getsize(out_path) / 1e6:.2f} MB), worst fp32 deviation {worst:.2e}")
 
+    # ---- rotary embedding: the restatement equals the reference's pure-torch apply_rotary_emb_torch
+    #      (flash_attn/layers/rotary.py:22-36) on fp32 inputs, positions = per-batch offsets (+ row) ------------------
+    from flash_attn.layers.rotary import apply_rotary_emb_torch  # noqa: E402  (reference package, stub extension)
+    gen = torch.Generator().manual_seed(77)
+    for interleaved in (False, True):
+        for per_row in (True, False):
+            x = torch.randn(3, 5, 2, 64, generator=gen)
+            ang = torch.rand(40, 16, generator=gen) * 6.28
+            cos, sin = torch.cos(ang), torch.sin(ang)
+            offs = torch.tensor([0, 7, 30], dtype=torch.int32)
+            pos = offs.long().view(3, 1) + (torch.arange(5).view(1, 5) if per_row else 0)
+            want = apply_rotary_emb_torch(x, cos[pos.expand(3, 5)], sin[pos.expand(3, 5)], interleaved=interleaved)
+            got = mine.apply_rotary_emb_ref(x, cos, sin, offs, interleaved=interleaved, per_row_positions=per_row)
+            assert torch.equal(want, got), ("rotary restatement", interleaved, per_row)
+    print("rotary restatement == reference apply_rotary_emb_torch (fp32, 4 variants)")
+
     # ---- backward fixtures: autograd through the reference oracle (tests/test_flash_attn.py:1071-1105) ----------
     grads = {}
     for name, c in GRAD_CASES.items():

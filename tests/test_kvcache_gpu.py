@@ -97,8 +97,9 @@ def test_kvcache_rejects_unbuilt_features_by_message():
     kc = torch.randn(1, 256, 2, 64, dtype=torch.bfloat16, device=DEV)
     with pytest.raises(RuntimeError, match="divisible by 256"):
         fa.flash_attn_with_kvcache(q, kc[:, :100], kc[:, :100], block_table=torch.zeros(1, 1, dtype=torch.int32, device=DEV))
-    with pytest.raises(RuntimeError, match="rotary"):
-        fa.flash_attn_with_kvcache(q, kc, kc, rotary_cos=torch.zeros(256, 16, device=DEV), rotary_sin=torch.zeros(256, 16, device=DEV))
+    with pytest.raises(RuntimeError, match="new key / value to be appended to KV cache must also be provided"):
+        fa.flash_attn_with_kvcache(q, kc, kc, rotary_cos=torch.zeros(256, 16, device=DEV, dtype=torch.bfloat16),
+                                   rotary_sin=torch.zeros(256, 16, device=DEV, dtype=torch.bfloat16))
     with pytest.raises(RuntimeError, match="seqlens_k must also be passed in"):
         fa.flash_attn_with_kvcache(q, kc, kc, k=q[:, :, :2], v=q[:, :, :2])
 
@@ -168,3 +169,46 @@ def test_varlen_paged_kv():
                                      upcast=False, reorder_ops=True)
         err = (out[qs].float().cpu() - ref[0].float()).abs().max().item()
         assert err <= 2 * (pt.float() - ref.float()).abs().max().item() + 1e-5, (i, err)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("interleaved", [False, True])
+@pytest.mark.parametrize("rotary_fraction", [0.5, 1.0])
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("paged", [False, True])
+@pytest.mark.parametrize("sq,sk,d", [(1, 512, 128), (4, 768, 64), (33, 512, 128)])
+def test_kvcache_rotary(sq, sk, d, paged, causal, rotary_fraction, interleaved, dtype):
+    """Rotary embedding of q and of the appended keys (tests/test_flash_attn.py:2005-2036): keys at position
+    cache_seqlens + i; queries at the same positions when causal, else all at cache_seqlens.  The cache comparison uses
+    the reference's rtol = atol = 1e-3 (:2160-2161)."""
+    fa = _api()
+    torch.manual_seed(sq + sk + int(rotary_fraction * 10))
+    b, h, hk = 2, 4, 2
+    rotary_dim = int(rotary_fraction * d) // 16 * 16
+    q = torch.randn(b, sq, h, d, dtype=dtype)
+    k_cache = torch.randn(b, sk, hk, d, dtype=dtype)
+    v_cache = torch.randn(b, sk, hk, d, dtype=dtype)
+    k = torch.randn(b, sq, hk, d, dtype=dtype)
+    v = torch.randn(b, sq, hk, d, dtype=dtype)
+    cache_seqlens = torch.randint(0, sk - sq + 1, (b,), dtype=torch.int32)
+    angle = torch.rand(sk, rotary_dim // 2) * 2 * 3.141592653589793
+    cos, sin = torch.cos(angle).to(dtype), torch.sin(angle).to(dtype)
+    q_ro = oracle.apply_rotary_emb_ref(q, cos, sin, cache_seqlens, interleaved, per_row_positions=causal)
+    k_ro = oracle.apply_rotary_emb_ref(k, cos, sin, cache_seqlens, interleaved, per_row_positions=True)
+    out_ref, out_pt, _, kc_ref, vc_ref, _ = _expected(q_ro, k_cache, v_cache, k_ro, v, cache_seqlens, None, causal=causal)
+    if paged:
+        kc, vc, table = _paged(k_cache, v_cache, 256, seed=5)
+        kc_d, vc_d, table_d = kc.to(DEV), vc.to(DEV), table.to(DEV)
+    else:
+        kc_d, vc_d, table_d = k_cache.to(DEV), v_cache.to(DEV), None
+    out = fa.flash_attn_with_kvcache(q.to(DEV), kc_d, vc_d, k.to(DEV), v.to(DEV), rotary_cos=cos.to(DEV),
+                                     rotary_sin=sin.to(DEV), cache_seqlens=cache_seqlens.to(DEV), block_table=table_d,
+                                     causal=causal, rotary_interleaved=interleaved)
+    err = (out.float().cpu() - out_ref.float()).abs().max().item()
+    bound = 3 * (out_pt.float() - out_ref.float()).abs().max().item() + 1e-5
+    assert err <= bound, f"out err {err:.3e} > {bound:.3e}"
+    if paged:
+        kp_want, vp_want, _ = _paged(kc_ref, vc_ref, 256, seed=5)
+        assert torch.allclose(kc_d.cpu().float(), kp_want.float(), rtol=1e-3, atol=1e-3) and torch.equal(vc_d.cpu(), vp_want)
+    else:
+        assert torch.allclose(kc_d.cpu().float(), kc_ref.float(), rtol=1e-3, atol=1e-3) and torch.equal(vc_d.cpu(), vc_ref)
