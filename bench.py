@@ -163,10 +163,25 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("FA_BENCH_FORCE_DIST"):  # (the env switch rehearses this path on one GPU)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        # RCCL prints a version banner on stdout when it initialises: keep stdout for the one JSON line
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(backend="nccl", device_id=device)
+            dist.barrier()  # one collective over RCCL/xGMI: brings the communicator up outside the timed region
+            torch.cuda.synchronize()
+            # the timing bracket is a host-side barrier (gloo): attention shards over batch, there is no data-path
+            # collective, and a device-side barrier would add its own kernel + launch latency to the measured time
+            timing_group = dist.new_group(backend="gloo")
+            dist.barrier(group=timing_group)
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     lib = _lib.load()
     if args.variant:
@@ -215,9 +230,9 @@ def main():
 
     # per-launch kernel durations from HIP events on the launch stream (torch's current stream)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    if dist is not None:
-        dist.barrier()
     torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier(group=timing_group)
     t0 = time.perf_counter()
     for a, b_ in ev:
         a.record()
@@ -225,11 +240,11 @@ def main():
         b_.record()
     torch.cuda.synchronize()
     if dist is not None:
-        dist.barrier()
+        dist.barrier(group=timing_group)
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=timing_group)
         elapsed = float(t.item())
     kernel_ms = sorted(a.elapsed_time(b_) for a, b_ in ev)
     avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
