@@ -166,6 +166,7 @@ def main():
     if world > 1 or os.environ.get("FA_BENCH_FORCE_DIST"):  # (the env switch rehearses this path on one GPU)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # single node; the container hostname may not resolve
         # RCCL prints a version banner on stdout when it initialises: keep stdout for the one JSON line
         sys.stdout.flush()
         saved_stdout = os.dup(1)
