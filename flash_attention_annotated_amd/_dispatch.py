@@ -26,7 +26,7 @@ def aligned(t):
 
 def launch(q, k, v, out, lse, *, varlen, batch, max_seqlen_q, max_seqlen_k, softmax_scale, causal, window_left,
            window_right, softcap, cu_seqlens_q=None, cu_seqlens_k=None, seqused_q=None, seqused_k=None,
-           q_descale=None, k_descale=None, v_descale=None, alibi_slopes=None, kv_batch_idx=None, block_table=None):
+           q_descale=None, k_descale=None, v_descale=None, alibi_slopes=None, kv_batch_idx=None, block_table=None, num_splits=1):
     """q/k/v/out: dense (b, s, h, d) or packed (total, h, d) tensors on one GPU, last stride 1, aligned()."""
     lib = _lib.load()
     prm = _lib.new_params()
@@ -68,6 +68,7 @@ def launch(q, k, v, out, lse, *, varlen, batch, max_seqlen_q, max_seqlen_k, soft
         prm.alibi_slopes = ptr(alibi_slopes)
         prm.alibi_slopes_batch_stride = alibi_slopes.stride(0) if alibi_slopes.dim() == 2 else 0
     prm.kv_batch_idx = ptr(kv_batch_idx)
+    prm.num_splits = int(num_splits)  # 1 = off (prefill entry points), 0 = library heuristic (decode), N = forced
     if block_table is not None:
         prm.block_table = ptr(block_table)
         prm.block_table_batch_stride = block_table.stride(0)
@@ -76,7 +77,7 @@ def launch(q, k, v, out, lse, *, varlen, batch, max_seqlen_q, max_seqlen_k, soft
     need = lib.fa_fwd_workspace_size(ctypes.byref(prm))
     if need < 0:
         raise RuntimeError(f"fa_fwd_workspace_size failed ({need}): {_lib.strerror(int(need))}")
-    if need > 0:  # fp8: scratch for the bf16 expansion, from torch's caching allocator (callee never allocates)
+    if need > 0:  # fp8 expansion / split-KV partials: scratch from torch's caching allocator (callee never allocates)
         workspace = torch.empty(int(need) + 256, dtype=torch.uint8, device=q.device)
         base = (workspace.data_ptr() + 255) // 256 * 256
         prm.workspace = ctypes.c_void_p(base)

@@ -197,6 +197,85 @@ Fp8Plan fp8_plan(const fa_fwd_params *p) {
     return pl;
 }
 
+int head_dim_tile(int d);
+int block_m_of(int variant, int d);
+
+// ---- split-KV plan (role of num_splits_heuristic / set_params_splitkv, csrc/flash_attn/flash_api.cpp:257-329) ---------
+// Only dense (non-varlen) 16-bit problems split.  Heuristic (num_splits == 0): split when the tiles leave most of the
+// 256 CUs idle, so that tiles x splits reaches ~2 workgroups per CU, with at least 4 key blocks (256 keys) per split.
+struct SplitPlan {
+    int splits;
+    int64_t o_bytes, lse_bytes, total;  // partial O (16-bit, (splits, b, sq, h, d)) and LSE (fp32, (splits, b, h, sq))
+};
+SplitPlan split_plan(const fa_fwd_params *p, int variant) {
+    SplitPlan sp{1, 0, 0, 0};
+    if (p->cu_seqlens_q || p->dtype == FA_DTYPE_FP8_E4M3 || p->seqlen_q <= 0 || p->seqlen_k <= 0) return sp;
+    int n = p->num_splits;
+    const int n_blocks = (p->seqlen_k + 63) / 64;
+    if (n == 0) {
+        if (p->block_table && (variant == 0 || variant == 3)) variant = 1;
+        const int bm = block_m_of(variant, p->d);
+        const int64_t tiles = (int64_t)((p->seqlen_q + bm - 1) / bm) * p->h * p->b;
+        n = 1;
+        if (tiles > 0 && tiles <= 128 && n_blocks >= 8) {
+            n = (int)std::min<int64_t>((512 + tiles - 1) / tiles, n_blocks / 4);
+            n = std::max(1, std::min(n, 64));
+        }
+    }
+    n = std::max(1, std::min(n, std::min(n_blocks, 128)));
+    if (n <= 1) return sp;
+    sp.splits = n;
+    const int64_t rows = (int64_t)p->b * p->seqlen_q;
+    sp.o_bytes = (n * rows * p->h * p->d * 2 + 255) & ~int64_t(255);
+    sp.lse_bytes = (n * rows * p->h * 4 + 255) & ~int64_t(255);
+    sp.total = sp.o_bytes + sp.lse_bytes;
+    return sp;
+}
+
+// ---- split-KV merge: out = sum_s w_s O_s / sum_s w_s, w_s = exp(lse_s - max lse); lse = max + log sum w.  One thread =
+// one 16-byte chunk of one (batch, row, head); splits with LSE = +inf (no key in their range) carry no weight.
+template <typename T>
+__global__ void combine_splits_kernel(const T *__restrict__ o_acc, const float *__restrict__ lse_acc, T *__restrict__ out,
+                                      float *__restrict__ lse_out, int splits, int b, int sq, int h, int d,
+                                      int64_t o_bs, int64_t o_rs, int64_t o_hs) {
+    const int chunks = d >> 3;
+    const int64_t total = (int64_t)b * sq * h * chunks;
+    const int64_t o_split = (int64_t)b * sq * h * d, lse_split = (int64_t)b * h * sq;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % chunks);
+        int64_t t = i / chunks;
+        const int hd = (int)(t % h);
+        t /= h;
+        const int row = (int)(t % sq);
+        const int bb = (int)(t / sq);
+        const int64_t lse_idx = ((int64_t)bb * h + hd) * sq + row;
+        float mx = -INFINITY;
+        for (int s = 0; s < splits; ++s) {
+            const float l = lse_acc[s * lse_split + lse_idx];
+            if (l != INFINITY) mx = fmaxf(mx, l);
+        }
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float wsum = 0.f;
+        if (mx != -INFINITY) {
+            for (int s = 0; s < splits; ++s) {
+                const float l = lse_acc[s * lse_split + lse_idx];
+                if (l == INFINITY) continue;
+                const float w = __expf(l - mx);
+                wsum += w;
+                float x[8];
+                unpack8<T>(*reinterpret_cast<const uint4 *>(o_acc + s * o_split + (((int64_t)bb * sq + row) * h + hd) * d + c * 8), x);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += w * x[j];
+            }
+            const float inv = 1.f / wsum;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] *= inv;
+        }
+        *reinterpret_cast<uint4 *>(out + bb * o_bs + row * o_rs + hd * o_hs + c * 8) = pack8<T>(acc);
+        if (c == 0) lse_out[lse_idx] = (mx == -INFINITY) ? INFINITY : mx + __logf(wsum);
+    }
+}
+
 int head_dim_tile(int d) {
     if (d <= 64) return 64;
     if (d <= 128) return 128;
@@ -215,7 +294,7 @@ int launch(const fa::KParams &kp, hipStream_t stream) {
         }
         attr_set.store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL(kernel, dim3(kp.grid), dim3(NWAVES * 64), smem, stream, kp);
+    hipLaunchKernelGGL(kernel, dim3(kp.grid * (kp.num_splits > 1 ? kp.num_splits : 1)), dim3(NWAVES * 64), smem, stream, kp);
     if (hipGetLastError() != hipSuccess) return FA_ERR_LAUNCH;
     return FA_OK;
 }
@@ -232,7 +311,7 @@ int launch_w64(const fa::KParams &kp, hipStream_t stream) {
         }
         attr_set.store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL(kernel, dim3(kp.grid), dim3(256), smem, stream, kp);
+    hipLaunchKernelGGL(kernel, dim3(kp.grid * (kp.num_splits > 1 ? kp.num_splits : 1)), dim3(256), smem, stream, kp);
     if (hipGetLastError() != hipSuccess) return FA_ERR_LAUNCH;
     return FA_OK;
 }
@@ -373,10 +452,12 @@ int fa_rotary_apply(const fa_rotary_params *p, void *stream_) {
 int64_t fa_fwd_workspace_size(const fa_fwd_params *p) {
     if (!p) return FA_ERR_NULL_POINTER;
     if (p->abi_version != FA_ABI_VERSION || p->struct_size != sizeof(fa_fwd_params)) return FA_ERR_BAD_ABI;
-    if (p->dtype != FA_DTYPE_FP8_E4M3) return 0;
     if (p->b <= 0 || p->h <= 0 || p->h_k <= 0 || p->d <= 0 || p->seqlen_q < 0 || p->seqlen_k < 0) return FA_ERR_BAD_SHAPE;
     if (p->cu_seqlens_q && (p->total_q < 0 || p->total_k < 0)) return FA_ERR_BAD_SHAPE;
-    return fp8_plan(p).total;
+    if (p->dtype == FA_DTYPE_FP8_E4M3) return fp8_plan(p).total;
+    int variant = p->kernel_variant ? p->kernel_variant : g_default_variant.load();
+    if (variant < 0 || variant > 3) variant = 0;
+    return split_plan(p, variant).total;
 }
 
 int fa_fwd_validate(const fa_fwd_params *p) {
@@ -415,6 +496,15 @@ int fa_fwd_validate(const fa_fwd_params *p) {
     if (fp8 && !empty && p->seqlen_k > 0) {
         if (!p->workspace || reinterpret_cast<uintptr_t>(p->workspace) % 256 != 0 ||
             (int64_t)p->workspace_bytes < fp8_plan(p).total)
+            return FA_ERR_WORKSPACE;
+    }
+    if (p->num_splits < 0) return FA_ERR_BAD_SHAPE;
+    if (!fp8 && !empty && p->seqlen_k > 0) {
+        int variant = p->kernel_variant ? p->kernel_variant : g_default_variant.load();
+        if (variant < 0 || variant > 3) variant = 0;
+        const SplitPlan sp = split_plan(p, variant);
+        if (sp.splits > 1 && (!p->workspace || reinterpret_cast<uintptr_t>(p->workspace) % 256 != 0 ||
+                              (int64_t)p->workspace_bytes < sp.total))
             return FA_ERR_WORKSPACE;
     }
     if (p->softcap < 0.f || std::isnan(p->softcap) || std::isnan(p->softmax_scale)) return FA_ERR_BAD_SHAPE;
@@ -494,6 +584,18 @@ int fa_fwd(const fa_fwd_params *p, void *stream_) {
     const int64_t grid = 8 * ((units + 7) / 8) * kp.unit_tiles;
     if (grid > 0x7fffffff) return FA_ERR_BAD_SHAPE;
     kp.grid = (int32_t)grid;
+    // split-KV: `splits` copies of the grid; partial results go to the workspace and are merged below
+    const SplitPlan sp = nothing ? SplitPlan{1, 0, 0, 0} : split_plan(p, variant);
+    kp.num_splits = sp.splits;
+    if (sp.splits > 1) {
+        if (grid * sp.splits > 0x7fffffff) return FA_ERR_BAD_SHAPE;
+        char *ws = static_cast<char *>(p->workspace);
+        kp.o = ws;
+        kp.lse = reinterpret_cast<float *>(ws + sp.o_bytes);
+        kp.o_row_stride = (int64_t)p->h * p->d; kp.o_head_stride = p->d; kp.o_batch_stride = kp.o_row_stride * p->seqlen_q;
+        kp.o_split_stride = kp.o_batch_stride * p->b;
+        kp.lse_split_stride = (int64_t)p->b * p->h * p->seqlen_q;
+    }
 
     // window normalisation: csrc/flash_attn/flash_api.cpp:396-402
     int wl = p->window_size_left, wr = p->window_size_right;
@@ -527,8 +629,23 @@ int fa_fwd(const fa_fwd_params *p, void *stream_) {
         kp.scale_log2 = p->softmax_scale * kLog2e;
     }
 
-    if (p->dtype == FA_DTYPE_BF16 || fp8) return dispatch_hdim<__bf16>(kp, softcap, variant, stream);  // fp8: out is bf16
-    return dispatch_hdim<_Float16>(kp, softcap, variant, stream);
+    const bool bf16 = p->dtype == FA_DTYPE_BF16 || fp8;  // fp8: out is bf16
+    const int st_main = bf16 ? dispatch_hdim<__bf16>(kp, softcap, variant, stream)
+                             : dispatch_hdim<_Float16>(kp, softcap, variant, stream);
+    if (st_main != FA_OK || sp.splits <= 1) return st_main;
+    // merge the partial results into the caller's out / softmax_lse
+    const int64_t total = (int64_t)p->b * p->seqlen_q * p->h * (p->d / 8);
+    const int blocks = (int)std::min<int64_t>((total + 255) / 256, 256 * 8);
+    if (bf16)
+        hipLaunchKernelGGL(combine_splits_kernel<__bf16>, dim3(blocks), dim3(256), 0, stream, static_cast<const __bf16 *>(kp.o),
+                           kp.lse, static_cast<__bf16 *>(p->o), p->softmax_lse, sp.splits, p->b, p->seqlen_q, p->h, p->d,
+                           p->o_batch_stride, p->o_row_stride, p->o_head_stride);
+    else
+        hipLaunchKernelGGL(combine_splits_kernel<_Float16>, dim3(blocks), dim3(256), 0, stream,
+                           static_cast<const _Float16 *>(kp.o), kp.lse, static_cast<_Float16 *>(p->o), p->softmax_lse,
+                           sp.splits, p->b, p->seqlen_q, p->h, p->d, p->o_batch_stride, p->o_row_stride, p->o_head_stride);
+    if (hipGetLastError() != hipSuccess) return FA_ERR_LAUNCH;
+    return FA_OK;
 }
 
 }  // extern "C"

@@ -67,7 +67,20 @@ struct KParams {
     const int32_t *kv_batch_idx;  // KV-cache decode: cache entry of each batch row (NULL = identity), dense only
     const int32_t *block_table;   // paged KV: page of key row j of batch i = block_table[i * bt_bs + j / page_size]
     int32_t bt_bs, page_size;     // (only the fwd_kernel shape reads paged caches: its tiles are 64-key aligned)
+    // split-KV: workgroup id = split * grid + (id inside one split's grid); split s handles the s-th part of the key
+    // blocks of its tile and writes a normalised partial O / LSE at o + s * o_split_stride, lse + s * lse_split_stride
+    int32_t num_splits;
+    int64_t o_split_stride, lse_split_stride;
 };
+
+// key-block range of split `split` out of p.num_splits (empty ranges are fine: O = 0, LSE = +inf, weight 0 in the merge)
+__device__ __forceinline__ void split_range(const KParams &p, int split, int &n_min, int &n_max) {
+    if (p.num_splits <= 1) return;
+    const int per = (n_max - n_min + p.num_splits - 1) / p.num_splits;
+    const int lo = n_min + split * per;
+    n_max = min(n_max, lo + per);
+    n_min = min(lo, n_max);
+}
 
 // per-workgroup effective scales for (batch, kv_head)
 struct Scales {
@@ -132,8 +145,9 @@ constexpr int BLOCK_N = 64;  // keys per K/V tile
 // one after the other.  Sharing workgroups hit one L2 (HBM traffic ~ algorithmic bytes), and XCDs get the same number of
 // units of every batch entry, which balances ragged batches (a contiguous split gave whole sequences to single XCDs).
 // Placement is a speed matter only.  Returns false for padding workgroups.
-__device__ __forceinline__ bool decode_tile(const KParams &p, int &m_block, int &head, int &batch) {
-    const int wg = blockIdx.x;
+__device__ __forceinline__ bool decode_tile(const KParams &p, int &m_block, int &head, int &batch, int &split) {
+    split = p.num_splits > 1 ? blockIdx.x / p.grid : 0;  // p.grid is a multiple of 8: the XCD of a tile does not depend on the split
+    const int wg = p.num_splits > 1 ? blockIdx.x % p.grid : blockIdx.x;
     const int xcd = wg & 7, slot = wg >> 3;
     const int unit = (slot / p.unit_tiles) * 8 + xcd;
     const int tile = unit * p.unit_tiles + slot % p.unit_tiles;
@@ -205,8 +219,8 @@ __global__ __launch_bounds__(NWAVES * 64, (D <= 128 ? 2 : 1)) void fwd_kernel(co
     const int r = lane & 31;
     const int hh = lane >> 5;
 
-    int m_block, head, batch;
-    if (!decode_tile(p, m_block, head, batch)) return;  // whole workgroup (padding)
+    int m_block, head, batch, split;
+    if (!decode_tile(p, m_block, head, batch, split)) return;  // whole workgroup (padding)
     const int kv_head = head / p.h_ratio;
 
     // ---- sequence bookkeeping (BlockInfo / SeqlenInfo role) --------------------------------------
@@ -240,6 +254,8 @@ __global__ __launch_bounds__(NWAVES * 64, (D <= 128 ? 2 : 1)) void fwd_kernel(co
     const Scales sc = load_scales(p, batch, kv_head);
     const float alibi = load_alibi(p, sc, batch, head);
 
+    o_base += split * p.o_split_stride;      // split-KV: partial results of split s (0 when off)
+    lse_base += split * p.lse_split_stride;
     if (p.block_table) k_base = v_base = 0;  // paged: the page supplies the batch offset
     const int32_t *pages = p.block_table ? p.block_table + (int64_t)batch * p.bt_bs : nullptr;
     const T *qp = (const T *)p.q + q_base + (int64_t)head * p.q_head_stride;
@@ -253,8 +269,9 @@ __global__ __launch_bounds__(NWAVES * 64, (D <= 128 ? 2 : 1)) void fwd_kernel(co
     int key_hi = sk, key_lo = 0;
     if (p.window_right >= 0) key_hi = min(sk, row_hi + shift + p.window_right);
     if (p.window_left >= 0) key_lo = max(0, row_lo + shift - p.window_left);
-    const int n_min = key_lo / BLOCK_N;
-    const int n_max = key_hi > 0 ? (key_hi + BLOCK_N - 1) / BLOCK_N : 0;
+    int n_min = key_lo / BLOCK_N;
+    int n_max = key_hi > 0 ? (key_hi + BLOCK_N - 1) / BLOCK_N : 0;
+    split_range(p, split, n_min, n_max);
 
     const int wrow = row_lo + wave * 32;          // first row of this wave
     const int my_row = wrow + r;                  // the query row this lane owns

@@ -351,7 +351,8 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     const int hh = lane >> 5;
 
     int m_block, head, batch;
-    if (!decode_tile(p, m_block, head, batch)) return;  // whole workgroup (padding)
+    int split;
+    if (!decode_tile(p, m_block, head, batch, split)) return;  // whole workgroup (padding)
     const int kv_head = head / p.h_ratio;
 
     int sq, sk;
@@ -382,6 +383,8 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     const int row_lo = m_block * BLOCK_M;
     if (row_lo >= sq) return;
 
+    o_base += split * p.o_split_stride;  // split-KV: partial results of split s (0 when off)
+    lse_base += split * p.lse_split_stride;
     const T *qp = (const T *)p.q + q_base + (int64_t)head * p.q_head_stride;
     const T *kp = (const T *)p.k + k_base + (int64_t)kv_head * p.k_head_stride;
     const T *vp = (const T *)p.v + v_base + (int64_t)kv_head * p.v_head_stride;
@@ -402,8 +405,10 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     int key_hi = sk, key_lo = 0;
     if (p.window_right >= 0) key_hi = min(sk, row_hi + shift + p.window_right);
     if (p.window_left >= 0) key_lo = max(0, row_lo + shift - p.window_left);
-    const int n_min = key_lo / BLOCK_N;
-    const int n_max = key_hi > 0 ? (key_hi + BLOCK_N - 1) / BLOCK_N : 0;
+    int n_min_ = key_lo / BLOCK_N;
+    int n_max_ = key_hi > 0 ? (key_hi + BLOCK_N - 1) / BLOCK_N : 0;
+    split_range(p, split, n_min_, n_max_);
+    const int n_min = n_min_, n_max = n_max_;
 
     const int wrow = row_lo + wave * 64;  // first row of this wave; q-block A = wrow.., B = wrow+32..
     const int row_a = wrow + r, row_b = wrow + 32 + r;

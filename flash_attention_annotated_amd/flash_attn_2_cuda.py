@@ -386,10 +386,10 @@ def fwd_kvcache(q: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor, k_:
                 is_rotary_interleaved: bool, num_splits: int) -> List[torch.Tensor]:
     """mha_fwd_kvcache, csrc/flash_attn/flash_api.cpp:1202-1476.  Returns [out, softmax_lse].
 
-    Built: in-place append of k_/v_ at seqlens_k_, attention over the first seqlens_k_ (+ appended) rows of each
-    cache entry, cache_batch_idx_, causal / window / softcap / ALiBi, the (b, 1, h) -> (b, ngroups, h_k) GQA swap
-    (:1277-1285).  num_splits is a performance hint and is ignored (no split-KV).  Rotary embedding, paged KV
-    (block_table_) and leftpad_k_ are rejected by message."""
+    Built: in-place append of k_/v_ at seqlens_k_ (keys optionally rotated), attention over the first seqlens_k_
+    (+ appended) rows of each cache entry, cache_batch_idx_, paged caches (block_table_, page size % 256 == 0),
+    causal / window / softcap / ALiBi, rotary embedding of q, the (b, 1, h) -> (b, ngroups, h_k) GQA swap (:1277-1285),
+    split-KV (num_splits: 0 = library heuristic, 1 = off, N = forced).  leftpad_k_ is rejected by message."""
     _lib.load()
     q_dtype = q.dtype
     _check(q_dtype in (torch.float16, torch.bfloat16), "FlashAttention only support fp16 and bf16 data type")
@@ -509,7 +509,7 @@ def fwd_kvcache(q: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor, k_:
                              max_seqlen_q=seqlen_q, max_seqlen_k=seqlen_k, softmax_scale=softmax_scale,
                              causal=is_causal, window_left=window_size_left, window_right=window_size_right,
                              softcap=softcap, seqused_k=seqused, alibi_slopes=alibi, kv_batch_idx=cache_batch_idx_,
-                             block_table=block_table_)
+                             block_table=block_table_, num_splits=num_splits)
             if oc is not out:
                 out.copy_(oc)
         else:

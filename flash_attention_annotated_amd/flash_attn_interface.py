@@ -326,7 +326,8 @@ def flash_attn_with_kvcache(q, k_cache, v_cache, k=None, v=None, rotary_cos=None
     rotary_cos / rotary_sin: (seqlen_ro, rotary_dim / 2): rotary embedding of the appended keys (position
     cache_seqlens + i) and of q (the same positions when causal / local, otherwise all rows at cache_seqlens);
     rotary_interleaved: pairs (2j, 2j+1) instead of (j, j + rotary_dim/2).
-    Not built (rejected by message): cache_leftpad; num_splits is ignored.
+    num_splits: 0 = heuristic (splits the key range when the tiles would leave most CUs idle), 1 = no split, N = N
+    splits.  Not built (rejected by message): cache_leftpad.
     Returns out (batch, seqlen_q, nheads, headdim) [, softmax_lse (batch, nheads, seqlen_q)]."""
     assert k_cache.stride(-1) == 1, "k_cache must have contiguous last dimension"
     assert v_cache.stride(-1) == 1, "v_cache must have contiguous last dimension"

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define FA_ABI_VERSION 6
+#define FA_ABI_VERSION 7
 
 /* element types of q/k/v (o has the same type; fp8 inputs produce bf16 o) */
 enum fa_dtype {
@@ -60,7 +60,7 @@ enum fa_status {
     FA_ERR_LAUNCH = -8,            /* hipLaunchKernel failed */
     FA_ERR_BAD_ABI = -9,           /* params->abi_version / struct size mismatch */
     FA_ERR_NO_DEVICE = -10,        /* not a gfx950 device */
-    FA_ERR_WORKSPACE = -11         /* fp8 inputs need params->workspace of fa_fwd_workspace_size() bytes */
+    FA_ERR_WORKSPACE = -11         /* fp8 inputs / split-KV need params->workspace of fa_fwd_workspace_size() bytes */
 };
 
 /*
@@ -145,7 +145,12 @@ typedef struct fa_fwd_params {
     const int32_t *block_table;
     int64_t block_table_batch_stride;
     int32_t page_block_size;
-    int32_t reserved0;
+    /* Split-KV (set_params_splitkv / num_splits_heuristic csrc/flash_attn/flash_api.cpp:257-329, combine kernel
+     * src/flash_fwd_kernel.h:1108-1290): 1 = off, N > 1 = the key range of every tile is cut into N parts computed by
+     * N workgroups and merged by a second launch, 0 = library heuristic (splits only dense problems with few tiles,
+     * i.e. decode).  Needs params->workspace of fa_fwd_workspace_size() bytes when the effective value is > 1.
+     * The default-initialised struct (0) therefore may split: callers without a workspace must pass 1. */
+    int32_t num_splits;
 } fa_fwd_params;
 
 /* Validate and enqueue the forward on `stream` (a hipStream_t; NULL = default

@@ -212,3 +212,31 @@ def test_kvcache_rotary(sq, sk, d, paged, causal, rotary_fraction, interleaved, 
         assert torch.allclose(kc_d.cpu().float(), kp_want.float(), rtol=1e-3, atol=1e-3) and torch.equal(vc_d.cpu(), vp_want)
     else:
         assert torch.allclose(kc_d.cpu().float(), kc_ref.float(), rtol=1e-3, atol=1e-3) and torch.equal(vc_d.cpu(), vc_ref)
+
+
+@pytest.mark.parametrize("num_splits", [0, 2, 5, 16])
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("b,sq,sk,h,hk,d", [(1, 1, 4096, 8, 2, 128), (2, 1, 1500, 4, 4, 64), (1, 7, 3000, 4, 1, 128),
+                                             (2, 16, 2048, 2, 2, 256), (1, 130, 1024, 4, 2, 64)])
+def test_kvcache_split_kv(b, sq, sk, h, hk, d, causal, num_splits):
+    """Split-KV (num_splits forced, or 0 = heuristic): the merged result obeys the same bound as the unsplit one, LSE
+    included; ragged cache_seqlens leave some splits without keys (weight 0 in the merge)."""
+    fa = _api()
+    torch.manual_seed(b * 100 + sq + num_splits)
+    q = torch.randn(b, sq, h, d, dtype=torch.bfloat16)
+    k_cache = torch.randn(b, sk, hk, d, dtype=torch.bfloat16)
+    v_cache = torch.randn(b, sk, hk, d, dtype=torch.bfloat16)
+    cache_seqlens = torch.randint(sq, sk + 1, (b,), dtype=torch.int32)
+    cache_seqlens[0] = max(sq, sk // 9)  # far shorter than the cache: most splits of this row are empty
+    out_ref, out_pt, lse_ref, _, _, _ = _expected(q, k_cache, v_cache, None, None, cache_seqlens, None, causal=causal)
+    out, lse = fa.flash_attn_with_kvcache(q.to(DEV), k_cache.to(DEV), v_cache.to(DEV), cache_seqlens=cache_seqlens.to(DEV),
+                                          causal=causal, num_splits=num_splits, return_softmax_lse=True)
+    err = (out.float().cpu() - out_ref.float()).abs().max().item()
+    bound = 3 * (out_pt.float() - out_ref.float()).abs().max().item() + 1e-5
+    assert err <= bound, f"out err {err:.3e} > {bound:.3e}"
+    fin = torch.isfinite(lse_ref)
+    assert torch.equal(torch.isfinite(lse.cpu()), fin)
+    assert (lse.cpu()[fin] - lse_ref[fin]).abs().max().item() <= 2e-3
+    out1 = fa.flash_attn_with_kvcache(q.to(DEV), k_cache.to(DEV), v_cache.to(DEV), cache_seqlens=cache_seqlens.to(DEV),
+                                      causal=causal, num_splits=1)
+    assert (out.float() - out1.float()).abs().max().item() <= 4 * bound  # split and unsplit agree to rounding
