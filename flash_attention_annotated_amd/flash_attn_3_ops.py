@@ -1,0 +1,95 @@
+"""`torch.ops.flash_attn_3.*`: the FA3 operator library (hopper/flash_api.cpp:1671-1768), defined with the reference's
+schema strings so that `hopper/flash_attn_interface.py:66` (`flash_attn_3_gpu.fwd(...)`) and exported graphs bind
+unchanged.  hopper/test_flash_attn.py::test_flash3_bw_compatibility (:1163-1201) pins these schemas: arguments may only
+be appended with defaults.  Implementations are registered for the GPU dispatch key (HIP devices use `CUDA` in
+PyTorch-ROCm) and route to flash_attn_3_cuda.fwd / flash_attn_2_cuda.bwd -> the C-ABI.
+"""
+import torch
+
+from . import flash_attn_2_cuda, flash_attn_3_cuda
+
+FWD_SCHEMA = (
+    "fwd(Tensor q, Tensor k, Tensor v, Tensor(k_new!)? k_new = None, Tensor(v_new!)? v_new = None, Tensor? q_v = None, "
+    "Tensor(out!)? out = None, Tensor? cu_seqlens_q = None, Tensor? cu_seqlens_k = None, Tensor? cu_seqlens_k_new = None, "
+    "Tensor? seqused_q = None, Tensor? seqused_k = None, int? max_seqlen_q = None, int? max_seqlen_k = None, "
+    "Tensor? page_table = None, Tensor? kv_batch_idx = None, Tensor? leftpad_k = None, Tensor? rotary_cos = None, "
+    "Tensor? rotary_sin = None, Tensor? seqlens_rotary = None, Tensor? q_descale = None, Tensor? k_descale = None, "
+    "Tensor? v_descale = None, float? softmax_scale = None, bool is_causal = False, int window_size_left = -1, "
+    "int window_size_right = -1, int attention_chunk = 0, float softcap = 0.0, bool is_rotary_interleaved = False, "
+    "Tensor? scheduler_metadata = None, int num_splits = 0, bool? pack_gqa = None, int sm_margin = 0) "
+    "-> (Tensor(out!), Tensor, Tensor, Tensor)")
+BWD_SCHEMA = (
+    "bwd(Tensor dout, Tensor q, Tensor k, Tensor v, Tensor out, Tensor softmax_lse, Tensor(dq!)? dq = None, "
+    "Tensor(dk!)? dk = None, Tensor(dv!)? dv = None, Tensor? cu_seqlens_q = None, Tensor? cu_seqlens_k = None, "
+    "Tensor? seqused_q = None, Tensor? seqused_k = None, int? max_seqlen_q = None, int? max_seqlen_k = None, "
+    "float? softmax_scale = None, bool is_causal = False, int window_size_left = -1, int window_size_right = -1, "
+    "float softcap = 0.0, bool deterministic = False, int sm_margin = 0) "
+    "-> (Tensor(dq!), Tensor(dk!), Tensor(dv!), Tensor, Tensor, Tensor, Tensor, Tensor)")
+COMBINE_SCHEMA = ("fwd_combine(Tensor out_partial, Tensor lse_partial, Tensor(out!)? out = None, ScalarType? out_dtype = None) "
+                  "-> (Tensor(out!), Tensor)")
+METADATA_SCHEMA = (
+    "get_scheduler_metadata(int batch_size, int max_seqlen_q, int max_seqlen_k, int num_heads, int num_heads_k, int headdim, "
+    "int headdim_v, ScalarType qkv_dtype, Tensor seqused_k, Tensor? cu_seqlens_q = None, Tensor? cu_seqlens_k = None, "
+    "Tensor? cu_seqlens_k_new = None, Tensor? seqused_q = None, Tensor? leftpad_k = None, int? page_size = None, "
+    "int max_seqlen_k_new = 0, bool is_causal = False, int window_size_left = -1, int window_size_right = -1, "
+    "int attention_chunk = 0, bool has_softcap = False, int num_splits = 0, bool? pack_gqa = None, int sm_margin = 0) -> Tensor")
+
+_lib = torch.library.Library("flash_attn_3", "DEF")
+for _schema in (FWD_SCHEMA, BWD_SCHEMA, COMBINE_SCHEMA, METADATA_SCHEMA):
+    _lib.define(_schema)
+
+
+def _fwd(q, k, v, k_new=None, v_new=None, q_v=None, out=None, cu_seqlens_q=None, cu_seqlens_k=None, cu_seqlens_k_new=None,
+         seqused_q=None, seqused_k=None, max_seqlen_q=None, max_seqlen_k=None, page_table=None, kv_batch_idx=None,
+         leftpad_k=None, rotary_cos=None, rotary_sin=None, seqlens_rotary=None, q_descale=None, k_descale=None,
+         v_descale=None, softmax_scale=None, is_causal=False, window_size_left=-1, window_size_right=-1,
+         attention_chunk=0, softcap=0.0, is_rotary_interleaved=False, scheduler_metadata=None, num_splits=0,
+         pack_gqa=None, sm_margin=0):
+    o, lse, _, _ = flash_attn_3_cuda.fwd(
+        q, k, v, k_new, v_new, q_v, out, cu_seqlens_q, cu_seqlens_k, cu_seqlens_k_new, seqused_q, seqused_k, max_seqlen_q,
+        max_seqlen_k, page_table, kv_batch_idx, leftpad_k, rotary_cos, rotary_sin, seqlens_rotary, q_descale, k_descale,
+        v_descale, softmax_scale, is_causal, window_size_left, window_size_right, attention_chunk, softcap,
+        is_rotary_interleaved, scheduler_metadata, num_splits, pack_gqa, sm_margin)
+    # out_accum / softmax_lse_accum: empty when the result was not produced by the split path (hopper/flash_api.cpp:1196)
+    return o, lse, torch.empty(0, dtype=torch.float32, device=q.device), torch.empty(0, dtype=torch.float32, device=q.device)
+
+
+def _bwd(dout, q, k, v, out, softmax_lse, dq=None, dk=None, dv=None, cu_seqlens_q=None, cu_seqlens_k=None, seqused_q=None,
+         seqused_k=None, max_seqlen_q=None, max_seqlen_k=None, softmax_scale=None, is_causal=False, window_size_left=-1,
+         window_size_right=-1, softcap=0.0, deterministic=False, sm_margin=0):
+    """mha_bwd, hopper/flash_api.cpp:1259-1570, on the FA2-shaped backward of this build (16-bit types)."""
+    if seqused_q is not None or seqused_k is not None:
+        raise RuntimeError("This flash attention build does not support seqused_q / seqused_k in the backward.")
+    if softmax_scale is None:
+        softmax_scale = q.shape[-1] ** (-0.5)
+    if cu_seqlens_q is not None:
+        dq, dk, dv, sd = flash_attn_2_cuda.varlen_bwd(dout, q, k, v, out, softmax_lse, dq, dk, dv, cu_seqlens_q, cu_seqlens_k,
+                                                     None, int(max_seqlen_q), int(max_seqlen_k), 0.0, softmax_scale, False,
+                                                     is_causal, window_size_left, window_size_right, softcap, deterministic,
+                                                     None, None)
+    else:
+        dq, dk, dv, sd = flash_attn_2_cuda.bwd(dout, q, k, v, out, softmax_lse, dq, dk, dv, None, 0.0, softmax_scale,
+                                               is_causal, window_size_left, window_size_right, softcap, deterministic,
+                                               None, None)
+    e = torch.empty(0, dtype=torch.float32, device=q.device)  # softmax_lse_log2, dq_accum, dk_accum, dv_accum: none here
+    return dq, dk, dv, sd, e, e.clone(), e.clone(), e.clone()
+
+
+def _fwd_combine(out_partial, lse_partial, out=None, out_dtype=None):
+    raise RuntimeError("flash_attn_3::fwd_combine is not built: split results are merged inside fa_fwd (num_splits)")
+
+
+def _get_scheduler_metadata(batch_size, max_seqlen_q, max_seqlen_k, num_heads, num_heads_k, headdim, headdim_v, qkv_dtype,
+                            seqused_k, cu_seqlens_q=None, cu_seqlens_k=None, cu_seqlens_k_new=None, seqused_q=None,
+                            leftpad_k=None, page_size=None, max_seqlen_k_new=0, is_causal=False, window_size_left=-1,
+                            window_size_right=-1, attention_chunk=0, has_softcap=False, num_splits=0, pack_gqa=None,
+                            sm_margin=0):
+    """The tile schedule of this build is computed inside the kernel (decode_tile): the metadata tensor is opaque to
+    callers and empty here; `fwd` ignores it (hopper/flash_api.cpp:520-669 builds a semaphore + per-batch split table)."""
+    return torch.zeros(1, dtype=torch.int32, device=seqused_k.device)
+
+
+_lib.impl("fwd", _fwd, "CUDA")
+_lib.impl("bwd", _bwd, "CUDA")
+_lib.impl("fwd_combine", _fwd_combine, "CUDA")
+_lib.impl("get_scheduler_metadata", _get_scheduler_metadata, "CUDA")

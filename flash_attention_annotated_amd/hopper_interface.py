@@ -1,9 +1,12 @@
 """FA3-flavoured public API — names, argument order and defaults of `hopper/flash_attn_interface.py`
-(`flash_attn_func` :507-585, `flash_attn_varlen_func` :588-633) on top of flash_attn_3_cuda.fwd.
+(`flash_attn_func` :507-585, `flash_attn_varlen_func` :588-633) on top of `torch.ops.flash_attn_3.fwd`
+(flash_attn_3_ops.py registers the library with the reference's schema; :10-14 of the reference does the same lookup).
 This is the surface that carries fp8 e4m3 inputs with per-(batch, kv head) descales (BASELINE config 5)."""
 import torch
 
-from . import flash_attn_3_cuda
+from . import flash_attn_3_ops  # noqa: F401  (defines torch.ops.flash_attn_3)
+
+flash_attn_3_gpu = torch.ops.flash_attn_3
 
 
 def maybe_contiguous(x):
@@ -18,7 +21,7 @@ def _flash_attn_forward(q, k, v, k_new, v_new, qv, out, cu_seqlens_q, cu_seqlens
     """hopper/flash_attn_interface.py:20-102"""
     q, k = [maybe_contiguous(x) for x in (q, k)]
     v = v.contiguous() if v.stride(-1) != 1 and v.stride(-3) != 1 else v
-    out, softmax_lse, *rest = flash_attn_3_cuda.fwd(
+    out, softmax_lse, *rest = flash_attn_3_gpu.fwd(
         q, k, v, k_new, v_new, qv, out, cu_seqlens_q, cu_seqlens_k, cu_seqlens_k_new, seqused_q, seqused_k,
         max_seqlen_q, max_seqlen_k, page_table, kv_batch_idx, leftpad_k, rotary_cos, rotary_sin, seqlens_rotary,
         q_descale, k_descale, v_descale, softmax_scale, causal, window_size[0], window_size[1], attention_chunk, softcap,

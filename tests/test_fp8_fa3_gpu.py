@@ -130,3 +130,29 @@ def test_fa3_rejections():
     q8 = torch.randn(1, 16, 2, 72, dtype=torch.bfloat16, device=DEV).to(FP8)
     with pytest.raises(RuntimeError, match="multiple of 16"):
         fa3.flash_attn_func(q8, q8, q8)
+
+
+def test_flash_attn_3_ops_fwd_and_bwd():
+    """torch.ops.flash_attn_3.fwd / .bwd with keyword defaults (the schema of hopper/flash_api.cpp:1672-1731)."""
+    import flash_attention_annotated_amd.hopper_interface  # noqa: F401
+    from oracle import attention_ref as oracle
+    torch.manual_seed(21)
+    q = torch.randn(2, 150, 4, 64, dtype=torch.bfloat16)
+    k = torch.randn(2, 180, 2, 64, dtype=torch.bfloat16)
+    v = torch.randn(2, 180, 2, 64, dtype=torch.bfloat16)
+    g = torch.randn(2, 150, 4, 64, dtype=torch.bfloat16)
+    out, lse, acc, lse_acc = torch.ops.flash_attn_3.fwd(q.cuda(), k.cuda(), v.cuda(), is_causal=True)
+    assert acc.numel() == 0 and lse_acc.numel() == 0
+    out_ref, _ = oracle.attention_ref(q, k, v, causal=True)
+    out_pt, _ = oracle.attention_ref(q, k, v, causal=True, upcast=False, reorder_ops=True)
+    assert (out.float().cpu() - out_ref.float()).abs().max().item() <= 2 * (out_pt.float() - out_ref.float()).abs().max().item() + 1e-5
+    dq, dk, dv, sd, *_ = torch.ops.flash_attn_3.bwd(g.cuda(), q.cuda(), k.cuda(), v.cuda(), out, lse, is_causal=True)
+    ql, kl, vl = (t.clone().requires_grad_(True) for t in (q, k, v))
+    ref = torch.autograd.grad(oracle.attention_ref(ql, kl, vl, causal=True)[0], (ql, kl, vl), g)
+    ql, kl, vl = (t.clone().requires_grad_(True) for t in (q, k, v))
+    pt = torch.autograd.grad(oracle.attention_ref(ql, kl, vl, causal=True, upcast=False, reorder_ops=True)[0], (ql, kl, vl), g)
+    for got, r, p_ in zip((dq, dk, dv), ref, pt):
+        assert (got.float().cpu() - r.float()).abs().max().item() <= 3 * (p_.float() - r.float()).abs().max().item() + 1e-4
+    meta = torch.ops.flash_attn_3.get_scheduler_metadata(2, 150, 180, 4, 2, 64, 64, torch.bfloat16,
+                                                          torch.full((2,), 180, dtype=torch.int32, device="cuda"))
+    assert meta.dtype == torch.int32
