@@ -203,6 +203,21 @@ int block_m_of(int variant, int d);
 // ---- split-KV plan (role of num_splits_heuristic / set_params_splitkv, csrc/flash_attn/flash_api.cpp:257-329) ---------
 // Only dense (non-varlen) 16-bit problems split.  Heuristic (num_splits == 0): split when the tiles leave most of the
 // 256 CUs idle, so that tiles x splits reaches ~2 workgroups per CU, with at least 4 key blocks (256 keys) per split.
+// Kernel shape for a problem.  0 = the library's choice: the 256-row software-pipelined kernel, except
+//  * paged caches -> the 64-key-aligned 8-wave shape (variant 1);
+//  * short dense query blocks (seqlen_q <= 128: decode steps, short prefill chunks) -> 4 waves x 32 rows (variant 2):
+//    a 256-row tile would leave 2-3 of its 4 waves without rows, and this shape fits two workgroups per CU
+//    (measured on decode b8 hq32/hkv8 cache 8192: 149 -> 59 us, b32: 255 -> 219 us).
+int effective_variant(const fa_fwd_params *p) {
+    int variant = p->kernel_variant ? p->kernel_variant : g_default_variant.load();
+    if (variant < 0 || variant > 3) variant = 0;
+    if (variant == 0 || variant == 3) {
+        if (p->block_table) variant = 1;
+        else if (!p->cu_seqlens_q && p->seqlen_q <= 128) variant = 2;
+    }
+    return variant;
+}
+
 struct SplitPlan {
     int splits;
     int64_t o_bytes, lse_bytes, total;  // partial O (16-bit, (splits, b, sq, h, d)) and LSE (fp32, (splits, b, h, sq))
@@ -213,12 +228,13 @@ SplitPlan split_plan(const fa_fwd_params *p, int variant) {
     int n = p->num_splits;
     const int n_blocks = (p->seqlen_k + 63) / 64;
     if (n == 0) {
-        if (p->block_table && (variant == 0 || variant == 3)) variant = 1;
         const int bm = block_m_of(variant, p->d);
         const int64_t tiles = (int64_t)((p->seqlen_q + bm - 1) / bm) * p->h * p->b;
+        // two workgroups of the 4-wave shape fit a CU: aim at ~4 per CU there, ~2 per CU for the 256-row kernel
+        const int64_t cap = (variant == 2) ? 512 : 128, target = (variant == 2) ? 1024 : 512;
         n = 1;
-        if (tiles > 0 && tiles <= 128 && n_blocks >= 8) {
-            n = (int)std::min<int64_t>((512 + tiles - 1) / tiles, n_blocks / 4);
+        if (tiles > 0 && tiles <= cap && n_blocks >= 8) {
+            n = (int)std::min<int64_t>((target + tiles - 1) / tiles, n_blocks / 4);
             n = std::max(1, std::min(n, 64));
         }
     }
@@ -455,9 +471,7 @@ int64_t fa_fwd_workspace_size(const fa_fwd_params *p) {
     if (p->b <= 0 || p->h <= 0 || p->h_k <= 0 || p->d <= 0 || p->seqlen_q < 0 || p->seqlen_k < 0) return FA_ERR_BAD_SHAPE;
     if (p->cu_seqlens_q && (p->total_q < 0 || p->total_k < 0)) return FA_ERR_BAD_SHAPE;
     if (p->dtype == FA_DTYPE_FP8_E4M3) return fp8_plan(p).total;
-    int variant = p->kernel_variant ? p->kernel_variant : g_default_variant.load();
-    if (variant < 0 || variant > 3) variant = 0;
-    return split_plan(p, variant).total;
+    return split_plan(p, effective_variant(p)).total;
 }
 
 int fa_fwd_validate(const fa_fwd_params *p) {
@@ -500,9 +514,7 @@ int fa_fwd_validate(const fa_fwd_params *p) {
     }
     if (p->num_splits < 0) return FA_ERR_BAD_SHAPE;
     if (!fp8 && !empty && p->seqlen_k > 0) {
-        int variant = p->kernel_variant ? p->kernel_variant : g_default_variant.load();
-        if (variant < 0 || variant > 3) variant = 0;
-        const SplitPlan sp = split_plan(p, variant);
+        const SplitPlan sp = split_plan(p, effective_variant(p));
         if (sp.splits > 1 && (!p->workspace || reinterpret_cast<uintptr_t>(p->workspace) % 256 != 0 ||
                               (int64_t)p->workspace_bytes < sp.total))
             return FA_ERR_WORKSPACE;
@@ -525,9 +537,7 @@ int fa_fwd(const fa_fwd_params *p, void *stream_) {
     if (st != FA_OK) return st;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
 
-    int variant = p->kernel_variant ? p->kernel_variant : g_default_variant.load();
-    if (variant < 0 || variant > 3) variant = 0;
-    if (p->block_table && (variant == 0 || variant == 3)) variant = 1;  // paged caches: the 64-key-aligned tile shape
+    const int variant = effective_variant(p);
     const int block_m = block_m_of(variant, p->d);
 
     fa::KParams kp{};
