@@ -19,14 +19,18 @@ int head_dim_tile_b(int d) {
 }
 
 template <typename K>
-int launch_kernel(K kernel, int smem, std::atomic<bool> &attr_set, int grid, int threads, const fa::BParams &bp,
+int launch_kernel(K kernel, int smem, std::atomic<uint64_t> &attr_set, int grid, int threads, const fa::BParams &bp,
                   hipStream_t stream) {
-    if (smem > 65536 && !attr_set.load(std::memory_order_acquire)) {
+    // the > 64 KiB dynamic-LDS opt-in is a per-device attribute of the kernel: one bit per device ordinal
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = uint64_t(1) << (dev & 63);
+    if (smem > 65536 && !(attr_set.load(std::memory_order_acquire) & bit)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) {
             (void)hipGetLastError();
             return FA_ERR_LAUNCH;
         }
-        attr_set.store(true, std::memory_order_release);
+        attr_set.fetch_or(bit, std::memory_order_release);
     }
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), smem, stream, bp);
     if (hipGetLastError() != hipSuccess) return FA_ERR_LAUNCH;
@@ -59,7 +63,7 @@ int run_bwd(fa::BParams bp, int rows_q_max, int rows_k_max, hipStream_t stream) 
     }
     // 2. dK, dV
     {
-        static std::atomic<bool> attr{false};
+        static std::atomic<uint64_t> attr{0};
         bp.num_blocks = (rows_k_max + 128 * NBK - 1) / (128 * NBK);
         const int64_t tiles = (int64_t)bp.num_blocks * bp.h_k * bp.b;
         if (tiles > 0x7fffffff) return FA_ERR_BAD_SHAPE;
@@ -74,7 +78,7 @@ int run_bwd(fa::BParams bp, int rows_q_max, int rows_k_max, hipStream_t stream) 
     }
     // 3. dQ
     {
-        static std::atomic<bool> attr{false};
+        static std::atomic<uint64_t> attr{0};
         bp.num_blocks = (rows_q_max + 128 * NBQ - 1) / (128 * NBQ);
         const int64_t tiles = (int64_t)bp.num_blocks * bp.h * bp.b;
         if (tiles > 0x7fffffff) return FA_ERR_BAD_SHAPE;

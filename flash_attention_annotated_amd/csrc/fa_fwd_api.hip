@@ -302,13 +302,17 @@ template <typename T, int D, int NWAVES, bool SOFTCAP>
 int launch(const fa::KParams &kp, hipStream_t stream) {
     constexpr int smem = fa::smem_bytes<D, NWAVES>();
     auto kernel = fa::fwd_kernel<T, D, NWAVES, SOFTCAP>;
-    static std::atomic<bool> attr_set{false};
-    if (smem > 65536 && !attr_set.load(std::memory_order_acquire)) {
+    // the > 64 KiB dynamic-LDS opt-in is a per-device attribute of the kernel: one bit per device ordinal
+    static std::atomic<uint64_t> attr_set{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = uint64_t(1) << (dev & 63);
+    if (smem > 65536 && !(attr_set.load(std::memory_order_acquire) & bit)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) {
             (void)hipGetLastError();
             return FA_ERR_LAUNCH;
         }
-        attr_set.store(true, std::memory_order_release);
+        attr_set.fetch_or(bit, std::memory_order_release);
     }
     hipLaunchKernelGGL(kernel, dim3(kp.grid * (kp.num_splits > 1 ? kp.num_splits : 1)), dim3(NWAVES * 64), smem, stream, kp);
     if (hipGetLastError() != hipSuccess) return FA_ERR_LAUNCH;
@@ -319,13 +323,17 @@ template <typename T, int D, bool SOFTCAP>
 int launch_w64(const fa::KParams &kp, hipStream_t stream) {
     constexpr int smem = fa::smem_bytes_w64<D>();
     auto kernel = fa::fwd_kernel_w64<T, D, SOFTCAP>;
-    static std::atomic<bool> attr_set{false};
-    if (smem > 65536 && !attr_set.load(std::memory_order_acquire)) {
+    // the > 64 KiB dynamic-LDS opt-in is a per-device attribute of the kernel: one bit per device ordinal
+    static std::atomic<uint64_t> attr_set{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = uint64_t(1) << (dev & 63);
+    if (smem > 65536 && !(attr_set.load(std::memory_order_acquire) & bit)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) {
             (void)hipGetLastError();
             return FA_ERR_LAUNCH;
         }
-        attr_set.store(true, std::memory_order_release);
+        attr_set.fetch_or(bit, std::memory_order_release);
     }
     hipLaunchKernelGGL(kernel, dim3(kp.grid * (kp.num_splits > 1 ? kp.num_splits : 1)), dim3(256), smem, stream, kp);
     if (hipGetLastError() != hipSuccess) return FA_ERR_LAUNCH;

@@ -340,9 +340,12 @@ __global__ __launch_bounds__(NWAVES * 64, (D <= 128 ? 2 : 1)) void fwd_kernel(co
         }
     };
 
-    // lane-constant pieces of the LDS read addresses
+    // lane-constant pieces of the LDS read addresses; everything else is an immediate or one XOR (a separate VGPR per
+    // swizzled address costs ~100 registers at D = 256): see fa_fwd_kernel_w64.h
     const int i16 = lane & 15;           // lane inside its 16-lane group
     const int g1 = (lane >> 4) & 1;      // which 16-column half of a 32-wide d block
+    const int kbase = lds_off<D>(r, hh);
+    const int vbase = lds_off<D>(4 * hh + (i16 >> 2), 2 * g1 + ((i16 >> 1) & 1)) + 8 * (i16 & 1);
 
     if (n_min < n_max) {
         load_tile(n_min);
@@ -382,7 +385,7 @@ __global__ __launch_bounds__(NWAVES * 64, (D <= 128 ? 2 : 1)) void fwd_kernel(co
             for (int i = 0; i < 16; ++i) { s[0][i] = 0.f; s[1][i] = 0.f; }
 #pragma unroll
             for (int ks = 0; ks < KSTEPS; ++ks) {
-                const int off = lds_off<D>(r, 2 * ks + hh);  // swizzle depends on row & 15 only
+                const int off = kbase ^ (32 * ks);  // = lds_off<D>(r, 2 ks + hh): the swizzle XORs chunk bits 0-3 only
                 const u32x4 kf0 = *(const u32x4 *)(kbuf + off);
                 const u32x4 kf1 = *(const u32x4 *)(kbuf + off + 32 * D * 2);
                 s[0] = Elem<T>::mma(kf0, qf[ks], s[0]);
@@ -467,9 +470,8 @@ __global__ __launch_bounds__(NWAVES * 64, (D <= 128 ? 2 : 1)) void fwd_kernel(co
                     u32x4 vf;
 #pragma unroll
                     for (int j2 = 0; j2 < 2; ++j2) {
-                        const int row = 16 * st + 8 * j2 + 4 * hh + (i16 >> 2);
-                        const int ch = db * 4 + 2 * g1 + ((i16 >> 1) & 1);
-                        const int off = lds_off<D>(row, ch) + 8 * (i16 & 1);
+                        // = lds_off<D>(16 st + 8 j2 + 4 hh + (i16 >> 2), 4 db + 2 g1 + ((i16 >> 1) & 1)) + 8 (i16 & 1)
+                        const int off = (vbase ^ (64 * db + 32 * j2)) + (16 * st + 8 * j2) * (D * 2);
                         const s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                             (__attribute__((address_space(3))) s16x4 *)(vbuf + off));
                         const u32x2 t2 = __builtin_bit_cast(u32x2, t);
