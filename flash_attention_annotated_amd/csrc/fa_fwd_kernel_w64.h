@@ -863,24 +863,29 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     };
     using I2 = std::integral_constant<int, 2>;
     int j = 0;
+    // A tile whose first half-step is jt may take the fast path when both its half-steps (and the one behind them) need
+    // no mask, and the tiles its LDS-DMA looks ahead to (K tile +3, V tile +2) lie wholly inside the sequence.
+    auto tile_ok = [&](int jt) { return jt + 2 <= fast_last && jt + 6 <= seq_last; };
     while (j < J) {
-        // generic until the next 3-tile boundary (at least one half-step: guarantees progress)
+        // generic until the next tile boundary (at least one half-step: guarantees progress)
         do {
             generic_half(j);
             ++j;
-        } while ((j % 6) != 0 && j < J);
-        if (j + 6 > fast_last || moved_a || redo_a) continue;
+        } while ((j & 1) != 0 && j < J);
+        if (!tile_ok(j) || moved_a || redo_a) continue;
         {   // B(j) must be safe to exponentiate with its stale max (inside the loop the look-ahead guarantees it)
             float xa, xb;
             rowmax16(sbx, m_b, xa, xb);
             if (__any((half_swap_max(fmaxf(xa, xb)) - m_b) * csc_arg > THR)) continue;
         }
-        // fast: three tiles (one turn of the LDS rings) per iteration; every fast tile issues 2 LD_PER_THREAD pieces,
-        // all of them wholly inside the sequence (j + 10 <= seq_last), one per slice of its first half-step
-        while (j + 6 <= fast_last && j + 10 <= seq_last) {
-            const int n = n_min + (j >> 1);
+        // fast: up to three tiles (one turn of the LDS rings) per iteration; the first turn starts at the ring slot of
+        // tile j/2 (`skip` slots are already behind us); every fast tile issues 2 LD_PER_THREAD LDS-DMA pieces, one per
+        // slice of its first half-step
+        int skip = (j >> 1) % 3;
+        while (tile_ok(j)) {
+            const int n = n_min + (j >> 1) - skip;  // the tile in ring slot 0 of this turn
             int done = 0;        // half-steps completed in this iteration
-            bool odd_exit = false;
+            bool odd_exit = false, x = false, stop = false;
             u32x4 kf0, kf1;      // first two K fragments of the next half-step (fetched behind the tile barrier)
             auto k_prefetch = [&](int kbuf) {
                 kf0 = *(const u32x4 *)(smem + kbuf * TILE_BYTES + (kbase ^ 0));
@@ -888,40 +893,50 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
             };
             auto k_src = [&](int m) { return kp + (int64_t)(m * BLOCK_N - 32) * k_rs64; };
             auto v_src = [&](int t) { return vp + (int64_t)(t * BLOCK_N) * v_rs64; };
-            k_prefetch(1);       // tile slot 0 reads K buffer 1
-            bool x = fast_half(I0{}, I0{}, sbx, sby, pax, pay, kf0, kf1, k_src(n + 3), v_src(n + 2));
-            done = 1; odd_exit = true;
-            if (!x) {
-                x = fast_half(I0{}, I1{}, sby, sbx, pay, pax, kf0, kf1, nullptr, nullptr);
-                if (!(FA_ABLATE & 8)) tile_barrier<2 * LD_PER_THREAD>();
-                done = 2; odd_exit = false;
+            if (skip <= 0) {
+                k_prefetch(1);       // tile slot 0 reads K buffer 1
+                x = fast_half(I0{}, I0{}, sbx, sby, pax, pay, kf0, kf1, k_src(n + 3), v_src(n + 2));
+                done += 1; odd_exit = true;
+                if (!x) {
+                    x = fast_half(I0{}, I1{}, sby, sbx, pay, pax, kf0, kf1, nullptr, nullptr);
+                    if (!(FA_ABLATE & 8)) tile_barrier<2 * LD_PER_THREAD>();
+                    done += 1; odd_exit = false;
+                }
             }
-            if (!x) {
-                k_prefetch(2);
-                x = fast_half(I1{}, I0{}, sbx, sby, pax, pay, kf0, kf1, k_src(n + 4), v_src(n + 3));
-                done = 3; odd_exit = true;
+            if (!x && skip <= 1) {
+                if (done != 0 && !tile_ok(j + done)) stop = true;
+                else {
+                    k_prefetch(2);
+                    x = fast_half(I1{}, I0{}, sbx, sby, pax, pay, kf0, kf1, k_src(n + 4), v_src(n + 3));
+                    done += 1; odd_exit = true;
+                    if (!x) {
+                        x = fast_half(I1{}, I1{}, sby, sbx, pay, pax, kf0, kf1, nullptr, nullptr);
+                        if (!(FA_ABLATE & 8)) tile_barrier<2 * LD_PER_THREAD>();
+                        done += 1; odd_exit = false;
+                    }
+                }
             }
-            if (!x) {
-                x = fast_half(I1{}, I1{}, sby, sbx, pay, pax, kf0, kf1, nullptr, nullptr);
-                if (!(FA_ABLATE & 8)) tile_barrier<2 * LD_PER_THREAD>();
-                done = 4; odd_exit = false;
-            }
-            if (!x) {
-                k_prefetch(0);
-                x = fast_half(I2{}, I0{}, sbx, sby, pax, pay, kf0, kf1, k_src(n + 5), v_src(n + 4));
-                done = 5; odd_exit = true;
-            }
-            if (!x) {
-                x = fast_half(I2{}, I1{}, sby, sbx, pay, pax, kf0, kf1, nullptr, nullptr);
-                if (!(FA_ABLATE & 8)) tile_barrier<2 * LD_PER_THREAD>();
-                done = 6; odd_exit = false;
+            if (!x && !stop) {
+                if (done != 0 && !tile_ok(j + done)) stop = true;
+                else {
+                    k_prefetch(0);
+                    x = fast_half(I2{}, I0{}, sbx, sby, pax, pay, kf0, kf1, k_src(n + 5), v_src(n + 4));
+                    done += 1; odd_exit = true;
+                    if (!x) {
+                        x = fast_half(I2{}, I1{}, sby, sbx, pay, pax, kf0, kf1, nullptr, nullptr);
+                        if (!(FA_ABLATE & 8)) tile_barrier<2 * LD_PER_THREAD>();
+                        done += 1; odd_exit = false;
+                    }
+                }
             }
             j += done;
+            skip = 0;
             in_flight = 2 * LD_PER_THREAD;
             if (x) {
                 if (odd_exit) to_canonical_after_odd();
                 break;
             }
+            if (stop) break;
         }
         drain_all();  // leaving the fast loop: compiler-visible code may touch the accumulators from here on
     }
