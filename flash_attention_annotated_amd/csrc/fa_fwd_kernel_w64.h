@@ -722,10 +722,12 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     constexpr float LIM = (THR > 0.f) ? (float)(1u << (int)THR) : 1.0f;
     // kf0/kf1: the first two K fragments of this half-step, fetched by the previous half-step (KB = 1) or by the
     // driver right behind the tile barrier (KB = 0); a KB = 0 half-step leaves the next one's in them.
-    // kdma / vdma: wave-uniform source bases of K tile n+3 / V tile n+2 (both wholly inside the sequence); their
-    // LDS-DMA pieces are issued one per slice of the KB = 0 half-step, behind the slice's MFMAs.
+    // kdma / vdma (+ per-lane byte offsets): wave-uniform source bases of K tile n+3 / V tile n+2; their LDS-DMA pieces
+    // are issued one per slice of the KB = 0 half-step, behind the slice's MFMAs.  Look-ahead tiles that reach past the
+    // sequence (or are not needed at all) are fetched with rows clamped to the last valid one, like the generic path.
     auto fast_half = [&](auto slot_c, auto kb_c, f32x16 &sb_cur, f32x16 &sb_nxt, u32x4 (&pa_cur)[2],
-                         u32x4 (&pa_nxt)[2], u32x4 &kf0, u32x4 &kf1, const T *kdma, const T *vdma) -> bool {
+                         u32x4 (&pa_nxt)[2], u32x4 &kf0, u32x4 &kf1, const T *kdma, const T *vdma,
+                         const uint32_t (&kdma_off)[LD_PER_THREAD], const uint32_t (&vdma_off)[LD_PER_THREAD]) -> bool {
         constexpr int SLOT = decltype(slot_c)::value, KB = decltype(kb_c)::value;
         constexpr uint32_t KDST = SLOT * TILE_BYTES, VDST = (3 + (SLOT + 2) % 3) * TILE_BYTES;
         const char *kb_base = smem + ((SLOT + 1) % 3) * TILE_BYTES + KB * (32 * ROWB);
@@ -781,7 +783,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
                         pb[e2 >> 3][(e2 & 7) >> 1] = Exp2Pair<T>::run(sb_cur[e2], sb_cur[e2 + 1], csc, mcb, ps0, ps1);
                 }
                 if (KB == 0 && ks < LD_PER_THREAD && !(FA_ABLATE & 4))
-                    lds_dma1(lds_wave + KDST + ks * 1024, kdma, koff[ks < LD_PER_THREAD ? ks : 0]);
+                    lds_dma1(lds_wave + KDST + ks * 1024, kdma, kdma_off[ks < LD_PER_THREAD ? ks : 0]);
                 kf0 = kf1;
                 kf1 = kf2;
                 __builtin_amdgcn_sched_barrier(0);
@@ -822,7 +824,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
                     if (t == NSTEP / 2) rowmax16(sb_nxt, m_b, nxa, nxb);  // look-ahead max of B(j+1)
                 }
                 if (KB == 0 && t < LD_PER_THREAD && !(FA_ABLATE & 4))
-                    lds_dma1(lds_wave + VDST + t * 1024, vdma, voff[t < LD_PER_THREAD ? t : 0]);
+                    lds_dma1(lds_wave + VDST + t * 1024, vdma, vdma_off[t < LD_PER_THREAD ? t : 0]);
                 vf = vf_next;
                 vf_next = vf_next2;
                 __builtin_amdgcn_sched_barrier(0);
@@ -844,7 +846,6 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     // last half-step index whose scores need no mask (for this wave), and the fast limit: every half-step
     // jj of a fast tile pair [j, j+4) needs jj + 1 <= fast_last
     int fast_last = -1;
-    const int seq_last = __builtin_amdgcn_readfirstlane((sk - n_min * BLOCK_N) / 32 - 1);  // last half-step wholly < sk
     if (!SOFTCAP && p.window_left < 0 && jend > 0 && !p.alibi) {
         int nomask = (sk - n_min * BLOCK_N) / 32 - 1;
         if (p.window_right >= 0) {
@@ -864,8 +865,8 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     using I2 = std::integral_constant<int, 2>;
     int j = 0;
     // A tile whose first half-step is jt may take the fast path when both its half-steps (and the one behind them) need
-    // no mask, and the tiles its LDS-DMA looks ahead to (K tile +3, V tile +2) lie wholly inside the sequence.
-    auto tile_ok = [&](int jt) { return jt + 2 <= fast_last && jt + 6 <= seq_last; };
+    // no mask.
+    auto tile_ok = [&](int jt) { return jt + 2 <= fast_last; };
     while (j < J) {
         // generic until the next tile boundary (at least one half-step: guarantees progress)
         do {
@@ -891,14 +892,29 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
                 kf0 = *(const u32x4 *)(smem + kbuf * TILE_BYTES + (kbase ^ 0));
                 kf1 = *(const u32x4 *)(smem + kbuf * TILE_BYTES + (kbase ^ 32));
             };
-            auto k_src = [&](int m) { return kp + (int64_t)(m * BLOCK_N - 32) * k_rs64; };
-            auto v_src = [&](int t) { return vp + (int64_t)(t * BLOCK_N) * v_rs64; };
+            // source of a look-ahead tile starting at key k0: base of its first (clamped) row + this lane's offsets
+            uint32_t ko[LD_PER_THREAD], vo[LD_PER_THREAD];
+            auto tile_src = [&](const T *seq, int rs, int64_t rs64, const uint32_t (&in_range)[LD_PER_THREAD], int k0,
+                                uint32_t (&off)[LD_PER_THREAD]) -> const T * {
+                const int base_row = min(max(k0, 0), sk - 1);
+                if (k0 >= 0 && k0 + BLOCK_N <= sk) {  // wave-uniform
+#pragma unroll
+                    for (int i = 0; i < LD_PER_THREAD; ++i) off[i] = in_range[i];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < LD_PER_THREAD; ++i)
+                        off[i] = (uint32_t)((min(max(k0 + ld_row[i], 0), sk - 1) - base_row) * rs + ld_col[i]) * 2u;
+                }
+                return seq + (int64_t)base_row * rs64;
+            };
+            auto k_src = [&](int m) { return tile_src(kp, k_rs, k_rs64, koff, m * BLOCK_N - 32, ko); };
+            auto v_src = [&](int t) { return tile_src(vp, v_rs, v_rs64, voff, t * BLOCK_N, vo); };
             if (skip <= 0) {
                 k_prefetch(1);       // tile slot 0 reads K buffer 1
-                x = fast_half(I0{}, I0{}, sbx, sby, pax, pay, kf0, kf1, k_src(n + 3), v_src(n + 2));
+                x = fast_half(I0{}, I0{}, sbx, sby, pax, pay, kf0, kf1, k_src(n + 3), v_src(n + 2), ko, vo);
                 done += 1; odd_exit = true;
                 if (!x) {
-                    x = fast_half(I0{}, I1{}, sby, sbx, pay, pax, kf0, kf1, nullptr, nullptr);
+                    x = fast_half(I0{}, I1{}, sby, sbx, pay, pax, kf0, kf1, nullptr, nullptr, ko, vo);
                     if (!(FA_ABLATE & 8)) tile_barrier<2 * LD_PER_THREAD>();
                     done += 1; odd_exit = false;
                 }
@@ -907,10 +923,10 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
                 if (done != 0 && !tile_ok(j + done)) stop = true;
                 else {
                     k_prefetch(2);
-                    x = fast_half(I1{}, I0{}, sbx, sby, pax, pay, kf0, kf1, k_src(n + 4), v_src(n + 3));
+                    x = fast_half(I1{}, I0{}, sbx, sby, pax, pay, kf0, kf1, k_src(n + 4), v_src(n + 3), ko, vo);
                     done += 1; odd_exit = true;
                     if (!x) {
-                        x = fast_half(I1{}, I1{}, sby, sbx, pay, pax, kf0, kf1, nullptr, nullptr);
+                        x = fast_half(I1{}, I1{}, sby, sbx, pay, pax, kf0, kf1, nullptr, nullptr, ko, vo);
                         if (!(FA_ABLATE & 8)) tile_barrier<2 * LD_PER_THREAD>();
                         done += 1; odd_exit = false;
                     }
@@ -920,10 +936,10 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
                 if (done != 0 && !tile_ok(j + done)) stop = true;
                 else {
                     k_prefetch(0);
-                    x = fast_half(I2{}, I0{}, sbx, sby, pax, pay, kf0, kf1, k_src(n + 5), v_src(n + 4));
+                    x = fast_half(I2{}, I0{}, sbx, sby, pax, pay, kf0, kf1, k_src(n + 5), v_src(n + 4), ko, vo);
                     done += 1; odd_exit = true;
                     if (!x) {
-                        x = fast_half(I2{}, I1{}, sby, sbx, pay, pax, kf0, kf1, nullptr, nullptr);
+                        x = fast_half(I2{}, I1{}, sby, sbx, pay, pax, kf0, kf1, nullptr, nullptr, ko, vo);
                         if (!(FA_ABLATE & 8)) tile_barrier<2 * LD_PER_THREAD>();
                         done += 1; odd_exit = false;
                     }
