@@ -448,6 +448,12 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
             Mfma<T>::o_zero(oa[db], z4);
             Mfma<T>::o_zero(ob[db], z4);
         }
+        // (hipcc may spill an accumulator to scratch right here: let the matrix pipe finish first)
+        if constexpr (DBLOCKS == 4)
+            asm volatile("s_nop 15\n\ts_nop 7" : "+a"(oa[0]), "+a"(oa[1]), "+a"(oa[2]), "+a"(oa[3]),
+                         "+a"(ob[0]), "+a"(ob[1]), "+a"(ob[2]), "+a"(ob[3]));
+        else
+            asm volatile("s_nop 15\n\ts_nop 7" : "+a"(oa[0]), "+a"(oa[1]), "+a"(ob[0]), "+a"(ob[1]));
     }
     float m_a = -INFINITY, m_b = -INFINITY;  // running max (unscaled scores)
     float l_a = 0.f, l_b = 0.f;              // running sums, partial per lane half
@@ -664,6 +670,11 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
         prep_scores(0, sa, sbx);
         softmax(sa, pax, m_a, l_a, alpha_a, moved_a);
         moved_a = false;  // O_A is still zero: nothing to rescale
+        // B's running max starts at the max of its first block (l_b stays 0): P_B(0) <= 1 whichever path exponentiates it,
+        // so the fast path may take over from the very first tile
+        float xa, xb;
+        rowmax16(sbx, m_b, xa, xb);
+        m_b = half_swap_max(fmaxf(xa, xb));
     }
     __syncthreads();  // every wave has read K tile n_min before tile n_min's end overwrites its buffer
 
@@ -867,17 +878,21 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     // A tile whose first half-step is jt may take the fast path when both its half-steps (and the one behind them) need
     // no mask.
     auto tile_ok = [&](int jt) { return jt + 2 <= fast_last; };
+    bool first = true;  // the prologue leaves the pipeline state a fast tile expects: tile 0 may go straight to the fast loop
     while (j < J) {
-        // generic until the next tile boundary (at least one half-step: guarantees progress)
-        do {
-            generic_half(j);
-            ++j;
-        } while ((j & 1) != 0 && j < J);
+        // generic until the next tile boundary (at least one half-step, except in front of tile 0: guarantees progress)
+        if (!(first && tile_ok(0))) {
+            do {
+                generic_half(j);
+                ++j;
+            } while ((j & 1) != 0 && j < J);
+        }
+        first = false;
         if (!tile_ok(j) || moved_a || redo_a) continue;
         {   // B(j) must be safe to exponentiate with its stale max (inside the loop the look-ahead guarantees it)
             float xa, xb;
             rowmax16(sbx, m_b, xa, xb);
-            if (__any((half_swap_max(fmaxf(xa, xb)) - m_b) * csc_arg > THR)) continue;
+            if (__any(!((half_swap_max(fmaxf(xa, xb)) - m_b) * csc_arg <= THR))) continue;  // (NaN from -inf - -inf: not safe)
         }
         // fast: up to three tiles (one turn of the LDS rings) per iteration; the first turn starts at the ring slot of
         // tile j/2 (`skip` slots are already behind us); every fast tile issues 2 LD_PER_THREAD LDS-DMA pieces, one per

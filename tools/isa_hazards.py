@@ -64,7 +64,8 @@ def scan(path, required=REQUIRED):
         elif op not in ('s_waitcnt',):
             last_trans = None
         # MFMA result read (or overwritten) by anything but a chained MFMA before the matrix pipe has written it
-        if ' ' in l and (op.startswith('v_') or op.startswith('ds_') or op.startswith('global_') or op.startswith('buffer_')):
+        if ' ' in l and (op.startswith('v_') or op.startswith('ds_') or op.startswith('global_') or op.startswith('buffer_')
+                         or op.startswith('scratch_')):
             toks = [t.strip().lstrip('-') for t in l.split(None, 1)[1].split(',')]
             touched = set()
             for t in toks:
