@@ -26,7 +26,7 @@ def aligned(t):
 
 def launch(q, k, v, out, lse, *, varlen, batch, max_seqlen_q, max_seqlen_k, softmax_scale, causal, window_left,
            window_right, softcap, cu_seqlens_q=None, cu_seqlens_k=None, seqused_q=None, seqused_k=None,
-           q_descale=None, k_descale=None, v_descale=None, alibi_slopes=None, kv_batch_idx=None, block_table=None, num_splits=1):
+           q_descale=None, k_descale=None, v_descale=None, alibi_slopes=None, kv_batch_idx=None, block_table=None, num_splits=1, leftpad_k=None):
     """q/k/v/out: dense (b, s, h, d) or packed (total, h, d) tensors on one GPU, last stride 1, aligned()."""
     lib = _lib.load()
     prm = _lib.new_params()
@@ -68,6 +68,7 @@ def launch(q, k, v, out, lse, *, varlen, batch, max_seqlen_q, max_seqlen_k, soft
         prm.alibi_slopes = ptr(alibi_slopes)
         prm.alibi_slopes_batch_stride = alibi_slopes.stride(0) if alibi_slopes.dim() == 2 else 0
     prm.kv_batch_idx = ptr(kv_batch_idx)
+    prm.leftpad_k = ptr(leftpad_k)
     prm.num_splits = int(num_splits)  # 1 = off (prefill entry points), 0 = library heuristic (decode), N = forced
     if block_table is not None:
         prm.block_table = ptr(block_table)

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, LIB_NAME)
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
-FA_ABI_VERSION = 7
+FA_ABI_VERSION = 8
 FA_DTYPE_FP16, FA_DTYPE_BF16, FA_DTYPE_FP8_E4M3 = 0, 1, 2
 
 # every symbol include/fa_fwd.h declares (tests check the .so exports all of them)
@@ -98,6 +98,7 @@ class FaFwdParams(ctypes.Structure):
         ("block_table_batch_stride", ctypes.c_int64),
         ("page_block_size", ctypes.c_int32),
         ("num_splits", ctypes.c_int32),
+        ("leftpad_k", ctypes.c_void_p),
     ]
 
 

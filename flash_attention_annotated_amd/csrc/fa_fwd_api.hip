@@ -532,6 +532,7 @@ int fa_fwd_validate(const fa_fwd_params *p) {
                             p->alibi_slopes_batch_stride > 0x7fffffff))
         return FA_ERR_BAD_STRIDE;
     if (p->kv_batch_idx && (p->cu_seqlens_q || fp8)) return FA_ERR_UNSUPPORTED;  // dense 16-bit caches only
+    if (p->leftpad_k && (p->block_table || fp8)) return FA_ERR_UNSUPPORTED;  // (:1396 "Paged KV and leftpad_k" not together)
     if (p->block_table) {
         if (fp8 || p->kv_batch_idx) return FA_ERR_UNSUPPORTED;  // "Paged KVcache does not support cache_batch_idx" (:1247)
         if (p->page_block_size <= 0 || p->page_block_size % 256 != 0) return FA_ERR_BAD_SHAPE;  // (:1265)
@@ -630,6 +631,7 @@ int fa_fwd(const fa_fwd_params *p, void *stream_) {
 
     kp.alibi = p->alibi_slopes;
     kp.alibi_bs = (int32_t)p->alibi_slopes_batch_stride;
+    kp.leftpad_k = p->leftpad_k;
     kp.kv_batch_idx = p->cu_seqlens_q ? nullptr : p->kv_batch_idx;
     kp.block_table = p->block_table;
     kp.bt_bs = (int32_t)p->block_table_batch_stride;

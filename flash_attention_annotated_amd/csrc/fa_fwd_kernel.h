@@ -71,6 +71,7 @@ struct KParams {
     // blocks of its tile and writes a normalised partial O / LSE at o + s * o_split_stride, lse + s * lse_split_stride
     int32_t num_splits;
     int64_t o_split_stride, lse_split_stride;
+    const int32_t *leftpad_k;  // rows of padding in front of each sequence's keys (NULL = none)
 };
 
 // key-block range of split `split` out of p.num_splits (empty ranges are fine: O = 0, LSE = +inf, weight 0 in the merge)
@@ -256,6 +257,12 @@ __global__ __launch_bounds__(NWAVES * 64, (D <= 128 ? 2 : 1)) void fwd_kernel(co
 
     o_base += split * p.o_split_stride;      // split-KV: partial results of split s (0 when off)
     lse_base += split * p.lse_split_stride;
+    if (p.leftpad_k) {  // left-padded keys: skip the padding rows, the valid length shrinks by as much
+        const int lp = p.leftpad_k[batch];
+        sk = max(sk - lp, 0);
+        k_base += (int64_t)lp * p.k_row_stride;
+        v_base += (int64_t)lp * p.v_row_stride;
+    }
     if (p.block_table) k_base = v_base = 0;  // paged: the page supplies the batch offset
     const int32_t *pages = p.block_table ? p.block_table + (int64_t)batch * p.bt_bs : nullptr;
     const T *qp = (const T *)p.q + q_base + (int64_t)head * p.q_head_stride;

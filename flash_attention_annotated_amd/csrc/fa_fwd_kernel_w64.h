@@ -385,6 +385,12 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
 
     o_base += split * p.o_split_stride;  // split-KV: partial results of split s (0 when off)
     lse_base += split * p.lse_split_stride;
+    if (p.leftpad_k) {  // left-padded keys: skip the padding rows, the valid length shrinks by as much
+        const int lp = p.leftpad_k[batch];
+        sk = max(sk - lp, 0);
+        k_base += (int64_t)lp * p.k_row_stride;
+        v_base += (int64_t)lp * p.v_row_stride;
+    }
     const T *qp = (const T *)p.q + q_base + (int64_t)head * p.q_head_stride;
     const T *kp = (const T *)p.k + k_base + (int64_t)kv_head * p.k_head_stride;
     const T *vp = (const T *)p.v + v_base + (int64_t)kv_head * p.v_head_stride;

@@ -63,6 +63,17 @@ def _check_alibi(alibi_slopes_, batch_size, num_heads):
     return alibi_slopes_
 
 
+def _check_leftpad(leftpad_k_, batch_size, paged):
+    """csrc/flash_attn/flash_api.cpp:1395-1403 (and :683-691 in mha_varlen_fwd)"""
+    if leftpad_k_ is None:
+        return
+    _check(not paged, "We don't support Paged KV and leftpad_k running at the same time yet")
+    _check(leftpad_k_.dtype == torch.int32, "leftpad_k must have dtype int32")
+    _check_device(leftpad_k_, "leftpad_k")
+    _check(leftpad_k_.is_contiguous(), "leftpad_k must be contiguous")
+    _check_shape(leftpad_k_, "leftpad_k", batch_size)
+
+
 def _check_block_table(block_table_, kcache, batch_size):
     """Paged KV (csrc/flash_attn/flash_api.cpp:554-560, 1245-1266): returns (page_block_size, max_num_blocks_per_seq)."""
     _check_device(block_table_, "block_table")
@@ -158,7 +169,6 @@ def varlen_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out_: Optional
     for t, n in ((q, "q"), (k, "k"), (v, "v"), (cu_seqlens_q, "cu_seqlens_q"), (cu_seqlens_k, "cu_seqlens_k")):
         _check_device(t, n)
     paged = block_table_ is not None
-    _check(leftpad_k_ is None, "This flash attention build does not support leftpad_k.")
     _check(q.stride(-1) == 1, "Input tensor must have contiguous last dimension")
     _check(k.stride(-1) == 1, "Input tensor must have contiguous last dimension")
     _check(v.stride(-1) == 1, "Input tensor must have contiguous last dimension")
@@ -193,6 +203,7 @@ def varlen_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out_: Optional
         _check_shape(v, "v", total_k, num_heads_k, head_size)
     _check_shape(cu_seqlens_q, "cu_seqlens_q", batch_size + 1)
     _check_shape(cu_seqlens_k, "cu_seqlens_k", batch_size + 1)
+    _check_leftpad(leftpad_k_, batch_size, paged)
     if seqused_k is not None:
         _check(seqused_k.dtype == torch.int32, "seqused_k must have dtype int32")
         _check_device(seqused_k, "seqused_k")
@@ -223,7 +234,7 @@ def varlen_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out_: Optional
                              max_seqlen_k=max_seqlen_k, softmax_scale=softmax_scale, causal=is_causal,
                              window_left=window_size_left, window_right=window_size_right, softcap=softcap,
                              cu_seqlens_q=cu_seqlens_q, cu_seqlens_k=cu_seqlens_k, seqused_k=seqused_k,
-                             alibi_slopes=alibi, block_table=block_table_)
+                             alibi_slopes=alibi, block_table=block_table_, leftpad_k=leftpad_k_)
             if oc is not out:
                 out.copy_(oc)
         elif total_q > 0:
@@ -389,7 +400,7 @@ def fwd_kvcache(q: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor, k_:
     Built: in-place append of k_/v_ at seqlens_k_ (keys optionally rotated), attention over the first seqlens_k_
     (+ appended) rows of each cache entry, cache_batch_idx_, paged caches (block_table_, page size % 256 == 0),
     causal / window / softcap / ALiBi, rotary embedding of q, the (b, 1, h) -> (b, ngroups, h_k) GQA swap (:1277-1285),
-    split-KV (num_splits: 0 = library heuristic, 1 = off, N = forced).  leftpad_k_ is rejected by message."""
+    split-KV (num_splits: 0 = library heuristic, 1 = off, N = forced), left-padded caches (leftpad_k_)."""
     _lib.load()
     q_dtype = q.dtype
     _check(q_dtype in (torch.float16, torch.bfloat16), "FlashAttention only support fp16 and bf16 data type")
@@ -401,7 +412,6 @@ def fwd_kvcache(q: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor, k_:
     paged = block_table_ is not None
     if paged:
         _check(cache_batch_idx_ is None, "Paged KVcache does not support cache_batch_idx")
-    _check(leftpad_k_ is None, "This flash attention build does not support leftpad_k.")
 
     batch_size, seqlen_q, num_heads, head_size_og = q.shape
     batch_size_c, seqlen_k, num_heads_k = kcache.shape[0], kcache.shape[1], kcache.shape[2]
@@ -461,6 +471,7 @@ def fwd_kvcache(q: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor, k_:
         _check_device(seqlens_k_, "seqlens_k")
         _check(seqlens_k_.is_contiguous(), "seqlens_k must be contiguous")
         _check_shape(seqlens_k_, "seqlens_k", batch_size)
+    _check_leftpad(leftpad_k_, batch_size, paged)
     if cache_batch_idx_ is not None:
         _check_device(cache_batch_idx_, "cache_batch_idx")
         _check(cache_batch_idx_.is_contiguous(), "cache_batch_idx must be contiguous")
@@ -509,7 +520,7 @@ def fwd_kvcache(q: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor, k_:
                              max_seqlen_q=seqlen_q, max_seqlen_k=seqlen_k, softmax_scale=softmax_scale,
                              causal=is_causal, window_left=window_size_left, window_right=window_size_right,
                              softcap=softcap, seqused_k=seqused, alibi_slopes=alibi, kv_batch_idx=cache_batch_idx_,
-                             block_table=block_table_, num_splits=num_splits)
+                             block_table=block_table_, num_splits=num_splits, leftpad_k=leftpad_k_)
             if oc is not out:
                 out.copy_(oc)
         else:

@@ -327,7 +327,7 @@ def flash_attn_with_kvcache(q, k_cache, v_cache, k=None, v=None, rotary_cos=None
     cache_seqlens + i) and of q (the same positions when causal / local, otherwise all rows at cache_seqlens);
     rotary_interleaved: pairs (2j, 2j+1) instead of (j, j + rotary_dim/2).
     num_splits: 0 = heuristic (splits the key range when the tiles would leave most CUs idle), 1 = no split, N = N
-    splits.  Not built (rejected by message): cache_leftpad.
+    splits.  cache_leftpad: (batch,) int32, rows of padding in front of each cache entry's keys.
     Returns out (batch, seqlen_q, nheads, headdim) [, softmax_lse (batch, nheads, seqlen_q)]."""
     assert k_cache.stride(-1) == 1, "k_cache must have contiguous last dimension"
     assert v_cache.stride(-1) == 1, "v_cache must have contiguous last dimension"

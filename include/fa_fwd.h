@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define FA_ABI_VERSION 7
+#define FA_ABI_VERSION 8
 
 /* element types of q/k/v (o has the same type; fp8 inputs produce bf16 o) */
 enum fa_dtype {
@@ -151,6 +151,11 @@ typedef struct fa_fwd_params {
      * i.e. decode).  Needs params->workspace of fa_fwd_workspace_size() bytes when the effective value is > 1.
      * The default-initialised struct (0) therefore may split: callers without a workspace must pass 1. */
     int32_t num_splits;
+
+    /* Left-padded keys (leftpad_k of mha_varlen_fwd / mha_fwd_kvcache, csrc/flash_attn/src/block_info.h:22-35): the first
+     * leftpad_k[i] key rows of batch i are padding -- the kernel starts reading at row leftpad_k[i] and the valid length
+     * becomes (seqused_k or the sequence length) - leftpad_k[i].  (b) int32 or NULL.  Not with block_table. */
+    const int32_t *leftpad_k;
 } fa_fwd_params;
 
 /* Validate and enqueue the forward on `stream` (a hipStream_t; NULL = default

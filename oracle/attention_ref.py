@@ -18,12 +18,16 @@ import torch
 
 
 def local_mask(seqlen_q, seqlen_k, window_size=(-1, -1), query_padding_mask=None, key_padding_mask=None,
-               device=None):
+               device=None, key_leftpad=None):
     """True where key j is NOT visible from query i.  Bottom-right aligned:
     visible iff  i + sk - sq - left <= j <= min(i + sk - sq + right, sk)   (tests/test_util.py:150-182).
     With padding masks sk / sq are the per-batch valid lengths and the result is (b,1,sq,sk)."""
     i = torch.arange(seqlen_q, device=device, dtype=torch.long).view(-1, 1)
     j = torch.arange(seqlen_k, device=device, dtype=torch.long).view(1, -1)
+    if key_leftpad is not None:  # columns count from the first real key of each batch entry (tests/test_util.py:166-169)
+        lp = key_leftpad.long().view(-1, 1, 1, 1)
+        j = j.view(1, 1, 1, -1).expand(lp.shape[0], 1, 1, seqlen_k)
+        j = torch.where(j >= lp, j - lp, 2 ** 32)
     sk = seqlen_k if key_padding_mask is None else key_padding_mask.sum(-1).view(-1, 1, 1, 1)
     sq = seqlen_q if query_padding_mask is None else query_padding_mask.sum(-1).view(-1, 1, 1, 1)
     left, right = window_size
@@ -35,7 +39,7 @@ def local_mask(seqlen_q, seqlen_k, window_size=(-1, -1), query_padding_mask=None
 
 
 def attn_bias_from_alibi_slopes(slopes, seqlen_q, seqlen_k, query_padding_mask=None, key_padding_mask=None,
-                                causal=False):
+                                causal=False, key_leftpad=None):
     """ALiBi bias (b, h, sq|1, sk) from fp32 slopes (b, h): tests/test_flash_attn.py:29-56.
     non-causal: -slope * |i + sk - sq - j| (sk, sq = per-batch valid lengths under padding masks);
     causal: slope * (j - seqlen_k + 1), the same for every row (equal to the general form up to a per-row constant,
@@ -46,6 +50,10 @@ def attn_bias_from_alibi_slopes(slopes, seqlen_q, seqlen_k, query_padding_mask=N
         return torch.arange(-seqlen_k + 1, 1, dtype=torch.float32, device=slopes.device) * sl
     i = torch.arange(seqlen_q, dtype=torch.long, device=slopes.device).view(-1, 1)
     j = torch.arange(seqlen_k, dtype=torch.long, device=slopes.device)
+    if key_leftpad is not None:  # columns count from the first real key; padding columns get a huge distance (:40-43)
+        lp = key_leftpad.long().view(-1, 1, 1, 1)
+        j = j.view(1, 1, 1, -1).expand(lp.shape[0], 1, 1, seqlen_k)
+        j = torch.where(j >= lp, j - lp, 2 ** 32)
     sk = seqlen_k if key_padding_mask is None else key_padding_mask.sum(-1).view(-1, 1, 1, 1)
     sq = seqlen_q if query_padding_mask is None else query_padding_mask.sum(-1).view(-1, 1, 1, 1)
     return -sl * torch.abs(i + sk - sq - j).to(slopes.dtype)
@@ -78,7 +86,7 @@ def apply_rotary_emb_ref(x, cos, sin, seqlen_offsets, interleaved=False, per_row
 
 def attention_ref(q, k, v, query_padding_mask=None, key_padding_mask=None, attn_bias=None, causal=False,
                   window_size=(-1, -1), softcap=0.0, upcast=True, reorder_ops=False, return_lse=False,
-                  q_descale=None, k_descale=None, v_descale=None, intermediate_dtype=None):
+                  q_descale=None, k_descale=None, v_descale=None, intermediate_dtype=None, key_leftpad=None):
     """Exact softmax attention.
 
     q: (b, sq, h, d); k, v: (b, sk, h_k, d) with h % h_k == 0 (kv head = q head // (h/h_k)).
@@ -116,7 +124,7 @@ def attention_ref(q, k, v, query_padding_mask=None, key_padding_mask=None, attn_
         scores = scores.masked_fill(~key_padding_mask.view(b, 1, 1, sk), float("-inf"))
     masked = None
     if window_size[0] >= 0 or window_size[1] >= 0:
-        masked = local_mask(sq, sk, window_size, query_padding_mask, key_padding_mask, q.device)
+        masked = local_mask(sq, sk, window_size, query_padding_mask, key_padding_mask, q.device, key_leftpad)
         scores = scores.masked_fill(masked, float("-inf"))
     if attn_bias is not None:
         scores = scores + attn_bias

@@ -159,6 +159,26 @@ def main():
     torch.save(golden, out_path)
     print(f"wrote {out_path} ({os.path.getsize(out_path) / 1e6:.2f} MB), worst fp32 deviation {worst:.2e}")
 
+    # ---- left-padded keys (key_leftpad of tests/test_util.py:150-182 and tests/test_flash_attn.py:29-56): restatement
+    #      == reference, mask and ALiBi bias
+    gen = torch.Generator().manual_seed(99)
+    ql = torch.randn(2, 5, 2, 32, generator=gen).to(torch.bfloat16)
+    kl = torch.randn(2, 40, 2, 32, generator=gen).to(torch.bfloat16)
+    vl = torch.randn(2, 40, 2, 32, generator=gen).to(torch.bfloat16)
+    lens, lpad = torch.tensor([33, 40]), torch.tensor([7, 0], dtype=torch.int32)
+    kmask = (torch.arange(40).view(1, -1) < lens.view(-1, 1)) & (torch.arange(40).view(1, -1) >= lpad.view(-1, 1))
+    sl = torch.rand(2, 2, generator=gen) * 0.3
+    for causal, window in ((True, (-1, -1)), (False, (6, 2)), (False, (-1, -1))):
+        b_ref = ref_alibi(sl, 5, 40, None, kmask, causal=causal, key_leftpad=lpad)
+        b_my = mine.attn_bias_from_alibi_slopes(sl, 5, 40, None, kmask, causal=causal, key_leftpad=lpad)
+        assert torch.equal(b_ref, b_my), ("alibi leftpad", causal)
+        for bias in (None, b_ref):
+            want = fa2.attention_ref(ql, kl, vl, None, kmask, bias, causal=causal, window_size=window, key_leftpad=lpad)[0]
+            got = mine.attention_ref(ql, kl, vl, None, kmask, attn_bias=bias, causal=causal, window_size=window,
+                                     key_leftpad=lpad)[0]
+            assert torch.equal(want, got), ("leftpad", causal, window, bias is not None)
+    print("key_leftpad restatement == reference (mask + ALiBi, 6 variants)")
+
     # ---- rotary embedding: the restatement equals the reference's pure-torch apply_rotary_emb_torch
     #      (flash_attn/layers/rotary.py:22-36) on fp32 inputs, positions = per-batch offsets (+ row) ------------------
     from flash_attn.layers.rotary import apply_rotary_emb_torch  # noqa: E402  (reference package, stub extension)

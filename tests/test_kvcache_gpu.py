@@ -240,3 +240,57 @@ def test_kvcache_split_kv(b, sq, sk, h, hk, d, causal, num_splits):
     out1 = fa.flash_attn_with_kvcache(q.to(DEV), k_cache.to(DEV), v_cache.to(DEV), cache_seqlens=cache_seqlens.to(DEV),
                                       causal=causal, num_splits=1)
     assert (out.float() - out1.float()).abs().max().item() <= 4 * bound  # split and unsplit agree to rounding
+
+
+@pytest.mark.parametrize("alibi", [False, True])
+@pytest.mark.parametrize("new_kv,rotary", [(False, False), (True, False), (True, True)])
+@pytest.mark.parametrize("causal,window", [(False, (-1, -1)), (True, (-1, -1)), (False, (30, 5))])
+@pytest.mark.parametrize("sq,sk,d", [(1, 600, 128), (6, 512, 64), (40, 384, 128)])
+def test_kvcache_leftpad(sq, sk, d, causal, window, new_kv, rotary, alibi):
+    """cache_leftpad (tests/test_flash_attn.py:1978-1992, 2094-2109): the first leftpad rows of each cache entry are
+    padding; masks, ALiBi distances and the bottom-right alignment count from the first real key; appended rows and
+    rotary positions stay absolute."""
+    fa = _api()
+    torch.manual_seed(sq * 3 + sk + d)
+    b, h, hk = 3, 4, 2
+    dtype = torch.bfloat16
+    sk_new = sq if new_kv else 0
+    q = torch.randn(b, sq, h, d, dtype=dtype)
+    k_cache = torch.randn(b, sk, hk, d, dtype=dtype)
+    v_cache = torch.randn(b, sk, hk, d, dtype=dtype)
+    k = torch.randn(b, sk_new, hk, d, dtype=dtype) if new_kv else None
+    v = torch.randn(b, sk_new, hk, d, dtype=dtype) if new_kv else None
+    cache_seqlens = torch.randint(max(sq, 8), sk - sk_new + 1, (b,), dtype=torch.int32)
+    leftpad = torch.stack([torch.randint(0, int(c), (1,), dtype=torch.int32)[0] for c in cache_seqlens]).to(torch.int32)
+    leftpad[0] = 0
+    cos = sin = None
+    q_in, k_in = q, k
+    if rotary:
+        angle = torch.rand(sk, d // 4) * 6.283185
+        cos, sin = torch.cos(angle).to(dtype), torch.sin(angle).to(dtype)
+        per_row = causal or window != (-1, -1)
+        q_in = oracle.apply_rotary_emb_ref(q, cos, sin, cache_seqlens, False, per_row_positions=per_row)
+        k_in = oracle.apply_rotary_emb_ref(k, cos, sin, cache_seqlens, False, per_row_positions=True)
+    # expectation: cache with the appended rows, keys valid in [leftpad, cache_seqlens + new)
+    kc, vc = k_cache.clone(), v_cache.clone()
+    ar = torch.arange(sk).view(1, -1)
+    if new_kv:
+        upd = (ar >= cache_seqlens.view(-1, 1)) & (ar < cache_seqlens.view(-1, 1) + sk_new)
+        kc[upd] = k_in.reshape(-1, hk, d)
+        vc[upd] = v.reshape(-1, hk, d)
+    mask = (ar < cache_seqlens.view(-1, 1) + sk_new) & (ar >= leftpad.view(-1, 1))
+    slopes = torch.rand(b, h) * 0.3 if alibi else None
+    bias = None if slopes is None else oracle.attn_bias_from_alibi_slopes(slopes, sq, sk, None, mask, key_leftpad=leftpad)
+    kw = dict(attn_bias=bias, causal=causal, window_size=window, key_leftpad=leftpad)
+    out_ref, _ = oracle.attention_ref(q_in, kc, vc, None, mask, **kw)
+    out_pt, _ = oracle.attention_ref(q_in, kc, vc, None, mask, **kw, upcast=False, reorder_ops=True)
+    kc_d, vc_d = k_cache.to(DEV), v_cache.to(DEV)
+    out = fa.flash_attn_with_kvcache(
+        q.to(DEV), kc_d, vc_d, None if k is None else k.to(DEV), None if v is None else v.to(DEV),
+        rotary_cos=None if cos is None else cos.to(DEV), rotary_sin=None if sin is None else sin.to(DEV),
+        cache_seqlens=cache_seqlens.to(DEV), cache_leftpad=leftpad.to(DEV), causal=causal, window_size=window,
+        rotary_interleaved=False, alibi_slopes=None if slopes is None else slopes.to(DEV))
+    err = (out.float().cpu() - out_ref.float()).abs().max().item()
+    bound = 3 * (out_pt.float() - out_ref.float()).abs().max().item() + 1e-5
+    assert err <= bound, f"out err {err:.3e} > {bound:.3e}"
+    assert torch.allclose(kc_d.cpu().float(), kc.float(), rtol=1e-3, atol=1e-3) and torch.equal(vc_d.cpu(), vc)
