@@ -55,9 +55,11 @@ int run_bwd(fa::BParams bp, int rows_q_max, int rows_k_max, hipStream_t stream) 
     {
         const int64_t rows = bp.cu_seqlens_q ? (int64_t)bp.total_q : (int64_t)bp.b * bp.seqlen_q;
         const int64_t items = rows * bp.h;
-        const int grid = (int)std::min<int64_t>((items + 255) / 256, 256 * 16);
+        constexpr int LPR = D / 8 > 32 ? 32 : D / 8;  // lanes per (row, head)
+        const int per_block = 256 / LPR;
+        const int grid = (int)std::min<int64_t>((items + per_block - 1) / per_block, 256 * 16);
         if (items > 0) {
-            hipLaunchKernelGGL((fa::bwd_dot_kernel<T>), dim3(grid), dim3(256), 0, stream, bp);
+            hipLaunchKernelGGL((fa::bwd_dot_kernel<T, LPR>), dim3(grid), dim3(256), 0, stream, bp);
             if (hipGetLastError() != hipSuccess) return FA_ERR_LAUNCH;
         }
     }

@@ -163,12 +163,19 @@ __device__ __forceinline__ void unpack2(uint32_t w, float &lo, float &hi) {
     }
 }
 
-// ---- D = rowsum(dO * O), fp32.  One thread per (row, head), 16-byte loads.  HBM-bound, ~2 % of the backward. -------
-template <typename T>
+// ---- D = rowsum(dO * O), fp32.  LPR lanes share one (row, head): 16-byte loads (a wave reads whole rows, coalesced),
+//      shuffle reduce.  HBM-bound. ------------------------------------------------------------------------------------
+template <typename T, int LPR>
 __global__ __launch_bounds__(256) void bwd_dot_kernel(const BParams p) {
     const int64_t rows_total = p.cu_seqlens_q ? (int64_t)p.total_q : (int64_t)p.b * p.seqlen_q;
     const int64_t items = rows_total * p.h;
-    for (int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x; item < items; item += (int64_t)gridDim.x * 256) {
+    const int sub = threadIdx.x % LPR;
+    const int64_t stride = (int64_t)gridDim.x * (256 / LPR);
+    const int64_t n_iter = (items + stride - 1) / stride;  // the same for every lane: the shuffles need all of them
+    for (int64_t n = 0; n < n_iter; ++n) {
+        const int64_t it = n * stride + (int64_t)blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
+        const bool live = it < items;
+        const int64_t item = live ? it : 0;
         const int head = (int)(item % p.h);
         const int64_t row = item / p.h;
         int64_t o_off, do_off, d_off;
@@ -185,7 +192,7 @@ __global__ __launch_bounds__(256) void bwd_dot_kernel(const BParams p) {
         const T *op = (const T *)p.o + o_off + (int64_t)head * p.o_head_stride;
         const T *gp = (const T *)p.dout + do_off + (int64_t)head * p.do_head_stride;
         float acc = 0.f;
-        for (int c = 0; c < p.d; c += 8) {
+        for (int c = sub * 8; c < p.d; c += LPR * 8) {
             const u32x4 a = *(const u32x4 *)(op + c);
             const u32x4 g = *(const u32x4 *)(gp + c);
             const uint32_t aw[4] = {a[0], a[1], a[2], a[3]}, gw[4] = {g[0], g[1], g[2], g[3]};
@@ -197,7 +204,9 @@ __global__ __launch_bounds__(256) void bwd_dot_kernel(const BParams p) {
                 acc += x0 * y0 + x1 * y1;
             }
         }
-        p.dsum[d_off] = acc;
+#pragma unroll
+        for (int m = LPR / 2; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+        if (live && sub == 0) p.dsum[d_off] = acc;
     }
 }
 
