@@ -12,6 +12,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def ensure_library_is_built():
+    """The in-tree C-ABI library is (re)built when missing or older than its sources (hipcc cross-compiles without a GPU;
+    a no-op otherwise).  The product itself never builds on demand: a missing library makes every entry point raise."""
+    from flash_attention_annotated_amd import _lib
+    _lib.build()
+
+
 @pytest.fixture(scope="session")
 def golden():
     import torch
