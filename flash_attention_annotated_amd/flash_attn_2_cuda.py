@@ -10,7 +10,8 @@ checks, output allocation, params — and enqueue the gfx950 kernel through the 
 `TORCH_CHECK` messages, raised as RuntimeError like c10::Error is.
 
 `bwd` / `varlen_bwd` do the same for mha_bwd (:767-971) / mha_varlen_bwd (:973-1200) through include/fa_bwd.h.
-`fwd_kvcache` covers the decode path (mha_fwd_kvcache :1202-1476) without rotary / paged KV / split-KV.
+`fwd_kvcache` covers the decode path (mha_fwd_kvcache :1202-1476): in-place append, rotary, cache_batch_idx, paged
+and left-padded caches, split-KV.  Dropout / return_softmax are rejected by message.
 """
 import math
 from typing import List, Optional
