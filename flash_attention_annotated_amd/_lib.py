@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, LIB_NAME)
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
-FA_ABI_VERSION = 8
+FA_ABI_VERSION = 9
 FA_DTYPE_FP16, FA_DTYPE_BF16, FA_DTYPE_FP8_E4M3 = 0, 1, 2
 
 # every symbol include/fa_fwd.h declares (tests check the .so exports all of them)
@@ -99,6 +99,10 @@ class FaFwdParams(ctypes.Structure):
         ("page_block_size", ctypes.c_int32),
         ("num_splits", ctypes.c_int32),
         ("leftpad_k", ctypes.c_void_p),
+        ("p_dropout", ctypes.c_float),
+        ("reserved1", ctypes.c_int32),
+        ("rng_state", ctypes.c_void_p),
+        ("s_dmask", ctypes.c_void_p),
     ]
 
 
@@ -144,7 +148,7 @@ class FaBwdParams(ctypes.Structure):
         + [("softmax_scale", ctypes.c_float), ("softcap", ctypes.c_float)]
         + [("is_causal", ctypes.c_int32), ("window_size_left", ctypes.c_int32), ("window_size_right", ctypes.c_int32)]
         + [("alibi_slopes", ctypes.c_void_p), ("alibi_slopes_batch_stride", ctypes.c_int64)]
-        + [("deterministic", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+        + [("deterministic", ctypes.c_int32), ("p_dropout", ctypes.c_float), ("rng_state", ctypes.c_void_p)]
     )
 
 

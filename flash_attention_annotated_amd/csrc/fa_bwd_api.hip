@@ -115,6 +115,8 @@ int fa_bwd_validate(const fa_bwd_params *p) {
     if (!p) return FA_ERR_NULL_POINTER;
     if (p->abi_version != FA_ABI_VERSION || p->struct_size != sizeof(fa_bwd_params)) return FA_ERR_BAD_ABI;
     if (p->dtype != FA_DTYPE_FP16 && p->dtype != FA_DTYPE_BF16) return FA_ERR_BAD_DTYPE;
+    if (!(p->p_dropout >= 0.f && p->p_dropout < 1.f)) return FA_ERR_BAD_SHAPE;
+    if (p->p_dropout > 0.f && (!p->rng_state || reinterpret_cast<uintptr_t>(p->rng_state) % 8 != 0)) return FA_ERR_NULL_POINTER;
     if (p->b <= 0 || p->h <= 0 || p->h_k <= 0 || p->seqlen_q < 0 || p->seqlen_k < 0) return FA_ERR_BAD_SHAPE;
     if (p->d <= 0 || p->d > 256 || p->d % 8 != 0) return FA_ERR_BAD_HEAD_DIM;
     if (p->h % p->h_k != 0) return FA_ERR_BAD_HEADS;
@@ -198,6 +200,9 @@ int fa_bwd(const fa_bwd_params *p, void *stream_) {
     bp.out_scale = p->softmax_scale;
     bp.alibi = p->alibi_slopes;
     bp.alibi_bs = (int32_t)p->alibi_slopes_batch_stride;
+    bp.drop_thr = p->p_dropout > 0.f ? std::min(254, (int)std::floor(255.0 * (1.0 - (double)p->p_dropout))) : 255;  // as fa_fwd
+    bp.rp_dropout = p->p_dropout > 0.f ? 1.f / (1.f - p->p_dropout) : 1.f;
+    bp.rng_state = p->rng_state;
 
     // seqlen_q == 0: dK = dV = 0 is written by the dK/dV pass (no query tile is visible); seqlen_k == 0: dQ = 0 likewise
     if (p->dtype == FA_DTYPE_BF16) return dispatch_bwd<__bf16>(bp, softcap, p->seqlen_q, p->seqlen_k, stream);

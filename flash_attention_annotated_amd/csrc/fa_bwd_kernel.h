@@ -90,6 +90,10 @@ struct BParams {
     float out_scale;       // softmax_scale: the factor of dQ and dK
     const float *alibi;
     int32_t alibi_bs;
+    // dropout (as KParams): keep iff fa_rand8 <= drop_thr (255 = off); every tile then takes the MASK form of the pointwise
+    int32_t drop_thr;
+    float rp_dropout;
+    const uint64_t *rng_state;
 };
 
 // Work list (batch, head, block) cut into units = all blocks of one (batch, head) (they stream the same operands);
@@ -214,7 +218,8 @@ __global__ __launch_bounds__(256) void bwd_dot_kernel(const BParams p) {
 // `visible` is only looked at when MASK (boundary tiles); rows past the end of q carry LSE = +inf, i.e. P = 0.
 template <bool SOFTCAP, bool MASK>
 __device__ __forceinline__ void bwd_point(const BParams &p, float x, float dp, float lse2, float dsum, float alibi2,
-                                          int rel /* i + sk - sq - j */, bool visible, float &pv, float &ds) {
+                                          int rel /* i + sk - sq - j */, bool visible, uint32_t seed_mix, int qi, int key,
+                                          float &pv, float &ds) {
     float t = 0.f, sl;
     if constexpr (SOFTCAP) {
         t = fast_tanh(x * p.softcap_pre);
@@ -225,8 +230,18 @@ __device__ __forceinline__ void bwd_point(const BParams &p, float x, float dp, f
     if (p.alibi) sl -= alibi2 * fabsf((float)rel);
     pv = __builtin_amdgcn_exp2f(sl);
     if constexpr (MASK) pv = visible ? pv : 0.f;
+    bool keep = true;
+    if constexpr (MASK) {
+        if (p.drop_thr < 255) {  // O = (keep . P / (1 - p)) V: dP picks up the same factor, D = rowsum(dO . O) still holds
+            keep = fa_rand8(seed_mix, (uint32_t)qi, (uint32_t)key) <= (uint32_t)p.drop_thr;
+            dp = keep ? dp * p.rp_dropout : 0.f;
+        }
+    }
     ds = pv * (dp - dsum);
     if constexpr (SOFTCAP) ds *= (1.f - t * t);
+    if constexpr (MASK) {
+        if (p.drop_thr < 255) pv = keep ? pv * p.rp_dropout : 0.f;  // the P that multiplies dO in dV
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -421,6 +436,7 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_kernel(const BParams p) {
 
         const int head = tile_head(it), row0 = tile_row0(it);
         const float alibi2 = p.alibi ? p.alibi[(int64_t)batch * p.alibi_bs + head] * LOG2E : 0.f;
+        const uint32_t seed_mix = p.drop_thr < 255 ? fa_seed_mix(p.rng_state, batch * p.h + head) : 0u;
         const char *qbuf = smem + cur * TILE_BYTES;
         const char *gbuf = smem + (2 + cur) * TILE_BYTES;
 
@@ -433,6 +449,7 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_kernel(const BParams p) {
         bool need_mask = (key_w0 + WKEYS > sk) || (row0 + BM > sq);
         if (p.window_right >= 0) need_mask = need_mask || (key_w0 + WKEYS - 1 > row0 + shift + p.window_right);
         if (p.window_left >= 0) need_mask = need_mask || (key_w0 < row0 + BM - 1 + shift - p.window_left);
+        need_mask = need_mask || (p.drop_thr < 255);
 
         if (!skip) {
 #pragma unroll
@@ -487,7 +504,7 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_kernel(const BParams p) {
                                     if (p.window_left >= 0) vis = vis && (rel <= p.window_left);
                                 }
                                 float pv, ds;
-                                bwd_point<SOFTCAP, MASK>(p, s[nb][i], dp[nb][i], lv[e], dsv[e], alibi2, rel, vis, pv, ds);
+                                bwd_point<SOFTCAP, MASK>(p, s[nb][i], dp[nb][i], lv[e], dsv[e], alibi2, rel, vis, seed_mix, qi, my_key, pv, ds);
                                 s[nb][i] = pv;
                                 dp[nb][i] = ds;
                             }
@@ -677,6 +694,7 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_kernel(const BParams p) {
         }
     }
     const float alibi2 = p.alibi ? p.alibi[(int64_t)batch * p.alibi_bs + head] * LOG2E : 0.f;
+    const uint32_t seed_mix = p.drop_thr < 255 ? fa_seed_mix(p.rng_state, batch * p.h + head) : 0u;
 
     f32x16 dq_acc[NB * DBLOCKS];  // [nb * DBLOCKS + db], AGPRs
     {
@@ -769,6 +787,7 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_kernel(const BParams p) {
         bool need_mask = (k0 + BLOCK_N > sk);
         if (p.window_right >= 0) need_mask = need_mask || (k0 + BLOCK_N - 1 > wrow + shift + p.window_right);
         if (p.window_left >= 0) need_mask = need_mask || (k0 < wrow + WROWS - 1 + shift - p.window_left);
+        need_mask = need_mask || (p.drop_thr < 255);
 
         if (!skip) {
             const char *kbuf = smem + cur * TILE_BYTES;
@@ -816,7 +835,7 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_kernel(const BParams p) {
                                 if (p.window_left >= 0) vis = vis && (rel <= p.window_left);
                             }
                             float pv, ds;
-                            bwd_point<SOFTCAP, MASK>(p, s[nb][i], dp[nb][i], lse2[nb], dsum[nb], alibi2, rel, vis, pv, ds);
+                            bwd_point<SOFTCAP, MASK>(p, s[nb][i], dp[nb][i], lse2[nb], dsum[nb], alibi2, rel, vis, seed_mix, my_row, key, pv, ds);
                             dp[nb][i] = ds;
                         }
                     }

@@ -211,6 +211,7 @@ int block_m_of(int variant, int d);
 int effective_variant(const fa_fwd_params *p) {
     int variant = p->kernel_variant ? p->kernel_variant : g_default_variant.load();
     if (variant < 0 || variant > 3) variant = 0;
+    if (p->p_dropout > 0.f) return 1;  // dropout lives in the compiler-scheduled shape only
     if (variant == 0 || variant == 3) {
         if (p->block_table) variant = 1;
         else if (!p->cu_seqlens_q && p->seqlen_q <= 128) variant = 2;
@@ -225,6 +226,7 @@ struct SplitPlan {
 SplitPlan split_plan(const fa_fwd_params *p, int variant) {
     SplitPlan sp{1, 0, 0, 0};
     if (p->cu_seqlens_q || p->dtype == FA_DTYPE_FP8_E4M3 || p->seqlen_q <= 0 || p->seqlen_k <= 0) return sp;
+    if (p->p_dropout > 0.f) return sp;  // (the reference does not split under dropout either: flash_api.cpp:307)
     int n = p->num_splits;
     const int n_blocks = (p->seqlen_k + 63) / 64;
     if (n == 0) {
@@ -531,6 +533,13 @@ int fa_fwd_validate(const fa_fwd_params *p) {
     if (p->alibi_slopes && (reinterpret_cast<uintptr_t>(p->alibi_slopes) % 4 != 0 || p->alibi_slopes_batch_stride < 0 ||
                             p->alibi_slopes_batch_stride > 0x7fffffff))
         return FA_ERR_BAD_STRIDE;
+    if (!(p->p_dropout >= 0.f && p->p_dropout < 1.f)) return FA_ERR_BAD_SHAPE;  // "p_dropout must be in [0, 1)"
+    if (p->p_dropout > 0.f) {
+        if (fp8 || p->block_table || p->kv_batch_idx || p->leftpad_k) return FA_ERR_UNSUPPORTED;  // training path only
+        if (!p->rng_state || reinterpret_cast<uintptr_t>(p->rng_state) % 8 != 0) return FA_ERR_NULL_POINTER;
+    } else if (p->s_dmask) {
+        return FA_ERR_UNSUPPORTED;  // the randval tensor only exists under dropout
+    }
     if (p->kv_batch_idx && (p->cu_seqlens_q || fp8)) return FA_ERR_UNSUPPORTED;  // dense 16-bit caches only
     if (p->leftpad_k && (p->block_table || fp8)) return FA_ERR_UNSUPPORTED;  // (:1396 "Paged KV and leftpad_k" not together)
     if (p->block_table) {
@@ -632,6 +641,12 @@ int fa_fwd(const fa_fwd_params *p, void *stream_) {
     kp.alibi = p->alibi_slopes;
     kp.alibi_bs = (int32_t)p->alibi_slopes_batch_stride;
     kp.leftpad_k = p->leftpad_k;
+    // dropout: keep iff randval <= floor(255 (1 - p)); 255 = everything kept = the branch is off
+    kp.drop_thr = p->p_dropout > 0.f ? (int32_t)std::floor(255.0 * (1.0 - (double)p->p_dropout)) : 255;
+    if (p->p_dropout > 0.f && kp.drop_thr >= 255) kp.drop_thr = 254;  // (p < 1/255 would otherwise switch it off)
+    kp.rp_dropout = p->p_dropout > 0.f ? 1.f / (1.f - p->p_dropout) : 1.f;
+    kp.rng_state = p->rng_state;
+    kp.s_dmask = p->s_dmask;
     kp.kv_batch_idx = p->cu_seqlens_q ? nullptr : p->kv_batch_idx;
     kp.block_table = p->block_table;
     kp.bt_bs = (int32_t)p->block_table_batch_stride;

@@ -72,7 +72,30 @@ struct KParams {
     int32_t num_splits;
     int64_t o_split_stride, lse_split_stride;
     const int32_t *leftpad_k;  // rows of padding in front of each sequence's keys (NULL = none)
+    // dropout: keep iff fa_rand8(...) <= drop_thr (255 = off); rp_dropout = 1 / (1 - p); s_dmask: optional uint8 randvals
+    const uint64_t *rng_state;
+    uint8_t *s_dmask;
+    int32_t drop_thr;
+    float rp_dropout;
 };
+
+// 8-bit counter-based random value of element (batch*h + head, query row, key) for the dropout decision: the three
+// coordinates and the (seed, offset) pair are mixed and pushed through a 32-bit avalanche (lowbias32).  Forward and
+// backward regenerate the same values.
+__device__ __forceinline__ uint32_t fa_rand8(uint32_t seed_mix, uint32_t row, uint32_t key) {
+    uint32_t x = seed_mix ^ (row * 0x9E3779B1u) ^ (key * 0x85EBCA77u + 0x165667B1u);
+    x ^= x >> 16; x *= 0x7FEB352Du;
+    x ^= x >> 15; x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return x >> 24;
+}
+__device__ __forceinline__ uint32_t fa_seed_mix(const uint64_t *rng_state, int bh) {
+    const uint64_t seed = rng_state[0], off = rng_state[1];
+    uint32_t x = (uint32_t)seed ^ (uint32_t)(seed >> 32) * 0x27D4EB2Fu ^ (uint32_t)off * 0xC2B2AE3Du ^ (uint32_t)(off >> 32);
+    x ^= (uint32_t)bh * 0x2545F491u;
+    x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12;
+    return x;
+}
 
 // key-block range of split `split` out of p.num_splits (empty ranges are fine: O = 0, LSE = +inf, weight 0 in the merge)
 __device__ __forceinline__ void split_range(const KParams &p, int split, int &n_min, int &n_max) {
@@ -254,6 +277,14 @@ __global__ __launch_bounds__(NWAVES * 64, (D <= 128 ? 2 : 1)) void fwd_kernel(co
     if (row_lo >= sq) return;  // whole workgroup: nothing to do (varlen / padded grid)
     const Scales sc = load_scales(p, batch, kv_head);
     const float alibi = load_alibi(p, sc, batch, head);
+    // dropout bookkeeping (only read when p.drop_thr < 255)
+    const uint32_t seed_mix = p.drop_thr < 255 ? fa_seed_mix(p.rng_state, batch * p.h + head) : 0u;
+    int64_t dmask_base = 0;  // s_dmask: dense (b, h, sq, sk), varlen (h, total_q, max_seqlen_k)
+    const int64_t dmask_rs = p.seqlen_k;
+    if (p.s_dmask) {
+        if (p.cu_seqlens_q) dmask_base = ((int64_t)head * p.total_q + p.cu_seqlens_q[batch]) * p.seqlen_k;
+        else dmask_base = ((int64_t)batch * p.h + head) * p.seqlen_q * (int64_t)p.seqlen_k;
+    }
 
     o_base += split * p.o_split_stride;      // split-KV: partial results of split s (0 when off)
     lse_base += split * p.lse_split_stride;
@@ -457,7 +488,19 @@ __global__ __launch_bounds__(NWAVES * 64, (D <= 128 ? 2 : 1)) void fwd_kernel(co
                     s[kb][i] = pv;
                     psum += pv;
                 }
-            l_run += psum;
+            l_run += psum;  // (the normaliser sums the probabilities BEFORE dropout)
+
+            if (p.drop_thr < 255) {  // wave-uniform: dropout of the probabilities that feed the PV product
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int key = k0 + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                        const uint32_t rv = fa_rand8(seed_mix, (uint32_t)my_row, (uint32_t)key);
+                        if (rv > (uint32_t)p.drop_thr) s[kb][i] = 0.f;
+                        if (p.s_dmask && my_row < sq && key < sk) p.s_dmask[dmask_base + (int64_t)my_row * dmask_rs + key] = (uint8_t)rv;
+                    }
+            }
 
             // ---- P^T fragments: accumulator registers ARE the B operand of O^T += V^T.P^T ------------
             u32x4 pf[4];
@@ -498,7 +541,7 @@ __global__ __launch_bounds__(NWAVES * 64, (D <= 128 ? 2 : 1)) void fwd_kernel(co
     // (the loop's last barrier has retired every K/V read, so the region can be reused)
     const float l_tot = half_swap_sum(l_run);
     const bool empty = (l_tot == 0.f) || (l_tot != l_tot);
-    const float inv = (empty ? 1.f : 1.f / l_tot) * sc.v_descale;
+    const float inv = (empty ? 1.f : 1.f / l_tot) * sc.v_descale * p.rp_dropout;
     if (wave_active) {
         if (hh == 0 && my_row < sq) {
             // csrc/flash_attn/src/softmax.h:178-180: +inf for rows with no valid key

@@ -45,11 +45,20 @@ def _check_shape(x, name, *shape):
     _check(tuple(x.shape) == tuple(shape), f"{name} must have shape ({', '.join(str(s) for s in shape)})")
 
 
-def _reject_unbuilt(p_dropout, return_softmax):
-    # accepted positionally like the reference; rejected by message like the reference does for
-    # compiled-out features (hopper/flash_api.cpp:1148-1165)
-    _check(p_dropout == 0.0, "This flash attention build does not support dropout.")
-    _check(not return_softmax, "return_softmax is only supported when p_dropout > 0.0")
+def _check_dropout(p_dropout, return_softmax):
+    """csrc/flash_attn/flash_api.cpp:131 (p_dropout < 1) and :428-431 (return_softmax needs dropout)."""
+    _check(0.0 <= p_dropout < 1.0, "p_dropout must be in [0, 1)")
+    if return_softmax:
+        _check(p_dropout > 0.0, "return_softmax is only supported when p_dropout > 0.0")
+
+
+def _dropout_state(p_dropout, gen_, device):
+    """The (seed, offset) pair of this call (role of philox_cuda_state, csrc/flash_attn/flash_api.cpp:486-493): two
+    int64 drawn ON THE DEVICE from gen_ / torch's default generator of `device` -- reproducible under
+    torch.manual_seed, advances the generator, never syncs the host.  Zeros when dropout is off, like the reference."""
+    if p_dropout <= 0.0:
+        return torch.zeros((2,), dtype=torch.int64, device=device)
+    return torch.randint(-(1 << 62), 1 << 62, (2,), dtype=torch.int64, device=device, generator=gen_)
 
 
 def _check_alibi(alibi_slopes_, batch_size, num_heads):
@@ -111,7 +120,7 @@ def fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out_: Optional[torch.
     _check(num_heads % num_heads_k == 0, "Number of heads in key/value must divide number of heads in query")
     if softcap > 0.0:
         _check(p_dropout == 0.0, "Softcapping does not support dropout for now")
-    _reject_unbuilt(p_dropout, return_softmax)
+    _check_dropout(p_dropout, return_softmax)
     alibi = _check_alibi(alibi_slopes_, batch_size, num_heads)
 
     # causal=true is the same as causal=false in this case (:402)
@@ -133,8 +142,11 @@ def fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out_: Optional[torch.
 
     with torch.cuda.device(q.device):
         softmax_lse = torch.empty((batch_size, num_heads, seqlen_q), dtype=torch.float32, device=q.device)
-        p = torch.empty((0,), dtype=q_dtype, device=q.device)
-        rng_state = torch.zeros((2,), dtype=torch.int64, device=q.device)
+        # return_softmax: the uint8 random values behind the dropout decisions, (b, h, seqlen_q, seqlen_k) -- the
+        # reference's ROCm convention (tests/test_flash_attn_ck.py:34-38: kept iff value <= floor(255 (1 - p)))
+        p = (torch.zeros((batch_size, num_heads, seqlen_q, seqlen_k), dtype=torch.uint8, device=q.device)
+             if return_softmax else torch.empty((0,), dtype=q_dtype, device=q.device))
+        rng_state = _dropout_state(p_dropout, gen_, q.device)
 
         if seqlen_k > 0 and seqlen_q > 0:
             qc, kc, vc = (x if _aligned(x) else x.contiguous() for x in (q, k, v))
@@ -142,7 +154,8 @@ def fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out_: Optional[torch.
             _dispatch.launch(qc, kc, vc, oc, softmax_lse, varlen=False, batch=batch_size, max_seqlen_q=seqlen_q,
                              max_seqlen_k=seqlen_k, softmax_scale=softmax_scale, causal=is_causal,
                              window_left=window_size_left, window_right=window_size_right, softcap=softcap,
-                             alibi_slopes=alibi)
+                             alibi_slopes=alibi, p_dropout=p_dropout, rng_state=rng_state if p_dropout > 0 else None,
+                             s_dmask=p if return_softmax else None)
             if oc is not out:
                 out.copy_(oc)
         elif seqlen_q > 0:
@@ -189,7 +202,9 @@ def varlen_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out_: Optional
     _check(num_heads % num_heads_k == 0, "Number of heads in key/value must divide number of heads in query")
     if softcap > 0.0:
         _check(p_dropout == 0.0, "Softcapping does not support dropout for now")
-    _reject_unbuilt(p_dropout, return_softmax)
+    _check_dropout(p_dropout, return_softmax)
+    if p_dropout > 0.0:
+        _check(not paged and leftpad_k_ is None, "dropout is not supported with a paged or left-padded KV cache")
     alibi = _check_alibi(alibi_slopes_, batch_size, num_heads)
 
     if max_seqlen_q == 1 and alibi_slopes_ is None:
@@ -222,8 +237,10 @@ def varlen_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out_: Optional
 
     with torch.cuda.device(q.device):
         softmax_lse = torch.empty((num_heads, total_q), dtype=torch.float32, device=q.device)
-        p = torch.empty((0,), dtype=q_dtype, device=q.device)
-        rng_state = torch.zeros((2,), dtype=torch.int64, device=q.device)
+        # return_softmax: uint8 random values, (h, total_q, max_seqlen_k) (tests/test_flash_attn_ck.py:40-62)
+        p = (torch.zeros((num_heads, total_q, max_seqlen_k), dtype=torch.uint8, device=q.device)
+             if return_softmax else torch.empty((0,), dtype=q_dtype, device=q.device))
+        rng_state = _dropout_state(p_dropout, gen_, q.device)
         if zero_tensors:
             out.zero_()
             softmax_lse.fill_(-math.inf)
@@ -235,7 +252,8 @@ def varlen_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out_: Optional
                              max_seqlen_k=max_seqlen_k, softmax_scale=softmax_scale, causal=is_causal,
                              window_left=window_size_left, window_right=window_size_right, softcap=softcap,
                              cu_seqlens_q=cu_seqlens_q, cu_seqlens_k=cu_seqlens_k, seqused_k=seqused_k,
-                             alibi_slopes=alibi, block_table=block_table_, leftpad_k=leftpad_k_)
+                             alibi_slopes=alibi, block_table=block_table_, leftpad_k=leftpad_k_, p_dropout=p_dropout,
+                             rng_state=rng_state if p_dropout > 0 else None, s_dmask=p if return_softmax else None)
             if oc is not out:
                 out.copy_(oc)
         elif total_q > 0:
@@ -286,7 +304,12 @@ def bwd(dout: torch.Tensor, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, o
     _check(num_heads % num_heads_k == 0, "Number of heads in key/value must divide number of heads in query")
     if softcap > 0.0:
         _check(p_dropout == 0.0, "Softcapping does not support dropout for now")
-    _check(p_dropout == 0.0, "This flash attention build does not support dropout.")
+    _check(0.0 <= p_dropout < 1.0, "p_dropout must be in [0, 1)")
+    if p_dropout > 0.0:  # the forward's (seed, offset); without it a fresh pair is drawn like the reference (:895-910)
+        if rng_state is None:
+            rng_state = _dropout_state(p_dropout, gen_, q.device)
+        _check(rng_state.dtype == torch.int64 and rng_state.numel() == 2 and rng_state.is_cuda and rng_state.is_contiguous(),
+               "rng_state must be a contiguous int64 CUDA tensor with 2 elements")
     alibi = _check_alibi(alibi_slopes_, batch_size, num_heads)
 
     _check_shape(q, "q", batch_size, seqlen_q, num_heads, head_size)
@@ -308,7 +331,8 @@ def bwd(dout: torch.Tensor, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, o
             _dispatch.launch_bwd(*ins, lse, *outs, softmax_d, varlen=False, batch=batch_size, max_seqlen_q=seqlen_q,
                                  max_seqlen_k=seqlen_k, softmax_scale=softmax_scale, causal=is_causal,
                                  window_left=window_size_left, window_right=window_size_right, softcap=softcap,
-                                 alibi_slopes=alibi, deterministic=deterministic)
+                                 alibi_slopes=alibi, deterministic=deterministic, p_dropout=p_dropout,
+                                 rng_state=rng_state if p_dropout > 0 else None)
             for dst, src in zip((dq, dk, dv), outs):
                 if dst is not src:
                     dst.copy_(src)
@@ -354,7 +378,12 @@ def varlen_bwd(dout: torch.Tensor, q: torch.Tensor, k: torch.Tensor, v: torch.Te
     _check(num_heads % num_heads_k == 0, "Number of heads in key/value must divide number of heads in query")
     if softcap > 0.0:
         _check(p_dropout == 0.0, "Softcapping does not support dropout for now")
-    _check(p_dropout == 0.0, "This flash attention build does not support dropout.")
+    _check(0.0 <= p_dropout < 1.0, "p_dropout must be in [0, 1)")
+    if p_dropout > 0.0:  # the forward's (seed, offset); without it a fresh pair is drawn like the reference (:895-910)
+        if rng_state is None:
+            rng_state = _dropout_state(p_dropout, gen_, q.device)
+        _check(rng_state.dtype == torch.int64 and rng_state.numel() == 2 and rng_state.is_cuda and rng_state.is_contiguous(),
+               "rng_state must be a contiguous int64 CUDA tensor with 2 elements")
     alibi = _check_alibi(alibi_slopes_, batch_size, num_heads)
 
     _check_shape(q, "q", total_q, num_heads, head_size)
@@ -380,7 +409,8 @@ def varlen_bwd(dout: torch.Tensor, q: torch.Tensor, k: torch.Tensor, v: torch.Te
                                  max_seqlen_q=max_seqlen_q, max_seqlen_k=max_seqlen_k, softmax_scale=softmax_scale,
                                  causal=is_causal, window_left=window_size_left, window_right=window_size_right,
                                  softcap=softcap, cu_seqlens_q=cu_seqlens_q, cu_seqlens_k=cu_seqlens_k,
-                                 alibi_slopes=alibi, deterministic=deterministic)
+                                 alibi_slopes=alibi, deterministic=deterministic, p_dropout=p_dropout,
+                                 rng_state=rng_state if p_dropout > 0 else None)
             for dst, src in zip((dq, dk, dv), outs):
                 if dst is not src:
                     dst.copy_(src)

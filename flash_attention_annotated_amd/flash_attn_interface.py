@@ -78,7 +78,7 @@ def _flash_attn_forward_fake(q, k, v, dropout_p, softmax_scale, causal, window_s
     softmax_lse = torch.empty((batch_size, num_heads, seqlen_q), dtype=torch.float32, device=q.device)
     p = torch.empty((0,), dtype=q.dtype, device=q.device)
     if return_softmax:
-        p = torch.empty((batch_size, num_heads, seqlen_q, seqlen_k), dtype=q.dtype, device=q.device)
+        p = torch.empty((batch_size, num_heads, seqlen_q, seqlen_k), dtype=torch.uint8, device=q.device)
     rng_state = torch.empty((2,), dtype=torch.int64, device=q.device)
     return out, softmax_lse, p, rng_state
 
@@ -165,7 +165,7 @@ def _flash_attn_varlen_forward_fake(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seq
     softmax_lse = torch.empty((num_heads, total_q), dtype=torch.float32, device=q.device)
     p = torch.empty((0,), dtype=q.dtype, device=q.device)
     if return_softmax:
-        p = torch.empty((batch_size, num_heads, max_seqlen_q, max_seqlen_k), dtype=q.dtype, device=q.device)
+        p = torch.empty((num_heads, q.shape[0], max_seqlen_k), dtype=torch.uint8, device=q.device)
     rng_state = torch.empty((2,), dtype=torch.int64, device=q.device)
     return out, softmax_lse, p, rng_state
 

@@ -72,7 +72,8 @@ typedef struct fa_bwd_params {
     int64_t alibi_slopes_batch_stride;
 
     int32_t deterministic; /* accepted; results are always bit-reproducible */
-    int32_t reserved;
+    float p_dropout;       /* as fa_fwd_params; rng_state must be the pair the forward used */
+    const uint64_t *rng_state;
 } fa_bwd_params;
 
 /* Validate and enqueue the backward on `stream`.  Returns FA_OK or a negative fa_status; asynchronous. */

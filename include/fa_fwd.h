@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define FA_ABI_VERSION 8
+#define FA_ABI_VERSION 9
 
 /* element types of q/k/v (o has the same type; fp8 inputs produce bf16 o) */
 enum fa_dtype {
@@ -156,6 +156,19 @@ typedef struct fa_fwd_params {
      * leftpad_k[i] key rows of batch i are padding -- the kernel starts reading at row leftpad_k[i] and the valid length
      * becomes (seqused_k or the sequence length) - leftpad_k[i].  (b) int32 or NULL.  Not with block_table. */
     const int32_t *leftpad_k;
+
+    /* Attention dropout (csrc/flash_attn/flash_api.cpp:486-493, src/dropout.h).  p_dropout in [0, 1): every probability
+     * is kept with probability ~(1 - p) and the kept ones scaled by 1 / (1 - p).  The decision for (batch, head, query i,
+     * key j) is an 8-bit counter-based random value r = fa_rand8(seed, offset, batch * h + head, i, j) compared with
+     * floor(255 (1 - p)): kept iff r <= floor(255 (1 - p)) -- the "randval" convention of the reference's ROCm tests
+     * (tests/test_flash_attn_ck.py:34-38).  rng_state: device pointer to {seed, offset} (2 x uint64), read by the
+     * kernel (no host sync), the same pair must be given to fa_bwd.  s_dmask (optional, testing): receives r as uint8,
+     * dense (b, h, seqlen_q, seqlen_k), varlen (h, total_q, seqlen_k [= max_seqlen_k]).  Dropout runs on the
+     * compiler-scheduled kernel shape (no split-KV). */
+    float p_dropout;
+    int32_t reserved1;
+    const uint64_t *rng_state;
+    uint8_t *s_dmask;
 } fa_fwd_params;
 
 /* Validate and enqueue the forward on `stream` (a hipStream_t; NULL = default

@@ -86,7 +86,7 @@ def apply_rotary_emb_ref(x, cos, sin, seqlen_offsets, interleaved=False, per_row
 
 def attention_ref(q, k, v, query_padding_mask=None, key_padding_mask=None, attn_bias=None, causal=False,
                   window_size=(-1, -1), softcap=0.0, upcast=True, reorder_ops=False, return_lse=False,
-                  q_descale=None, k_descale=None, v_descale=None, intermediate_dtype=None, key_leftpad=None):
+                  q_descale=None, k_descale=None, v_descale=None, intermediate_dtype=None, key_leftpad=None, dropout_p=0.0, dropout_mask=None):
     """Exact softmax attention.
 
     q: (b, sq, h, d); k, v: (b, sk, h_k, d) with h % h_k == 0 (kv head = q head // (h/h_k)).
@@ -135,9 +135,11 @@ def attention_ref(q, k, v, query_padding_mask=None, key_padding_mask=None, attn_
     if query_padding_mask is not None:
         attention = attention.masked_fill(~query_padding_mask.view(b, 1, sq, 1), 0.0)
     attention_pv = attention
+    if dropout_mask is not None:  # (b, h, sq, sk) bool, True = kept; the 1/(1-p) goes onto v (tests/test_util.py:262-269)
+        attention_pv = attention.masked_fill(~dropout_mask, 0.0)
     if intermediate_dtype is not None:  # P rounded through e.g. e4m3 (hopper/test_util.py:343-344)
         attention_pv = attention.to(intermediate_dtype).to(attention.dtype)
-    out = torch.einsum("bhts,bshd->bthd", attention_pv, v)
+    out = torch.einsum("bhts,bshd->bthd", attention_pv, v * (1.0 / (1 - dropout_p)))
     if query_padding_mask is not None:
         out = out.masked_fill(~query_padding_mask.view(b, sq, 1, 1), 0.0)
     if key_padding_mask is not None:

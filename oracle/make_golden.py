@@ -231,6 +231,33 @@ def main():
         }
         errs = [(pt[i].float() - ref[i].float()).abs().max().item() for i in (1, 2, 3)]
         print(f"{name:34s} |d*_pt - d*_ref| = {errs[0]:.2e} {errs[1]:.2e} {errs[2]:.2e}")
+    # ---- dropout (tests/test_util.py:262-269): with the SAME keep-mask the restatement equals the reference, output
+    #      and gradients; the case is kept as a fixture (mask included) for tests/test_oracle.py --------------------
+    gen = torch.Generator().manual_seed(4242)
+    qd = torch.randn(2, 64, 4, 32, generator=gen).to(torch.bfloat16)
+    kd = torch.randn(2, 96, 2, 32, generator=gen).to(torch.bfloat16)
+    vd = torch.randn(2, 96, 2, 32, generator=gen).to(torch.bfloat16)
+    gd = torch.randn(2, 64, 4, 32, generator=gen).to(torch.bfloat16)
+    p_drop = 0.17
+    keep = torch.rand(2, 4, 64, 96, generator=gen) > p_drop
+    for causal in (False, True):
+        def run_d(fn, **extra):
+            ql, kl, vl = (t.clone().requires_grad_(True) for t in (qd, kd, vd))
+            out = fn(ql, kl, vl, None, None, dropout_p=p_drop, dropout_mask=keep, causal=causal, **extra)[0]
+            return (out.detach(),) + torch.autograd.grad(out, (ql, kl, vl), gd)
+        ref = run_d(fa2.attention_ref)
+        pt = run_d(fa2.attention_ref, upcast=False, reorder_ops=True)
+        my = run_d(mine.attention_ref)
+        my_pt = run_d(mine.attention_ref, upcast=False, reorder_ops=True)
+        for a, b_, what in zip(ref + pt, my + my_pt, ("out", "dq", "dk", "dv") * 2):
+            assert torch.equal(a, b_), ("dropout", causal, what)
+        grads[f"dropout_pin_causal{int(causal)}"] = {
+            "q": qd, "k": kd, "v": vd, "g": gd, "keep": keep, "p_dropout": p_drop, "causal": causal,
+            "out_ref": ref[0], "dq_ref": ref[1], "dk_ref": ref[2], "dv_ref": ref[3],
+            "out_pt": pt[0], "dq_pt": pt[1], "dk_pt": pt[2], "dv_pt": pt[3],
+        }
+    print("dropout restatement == reference (out + grads, fp32 and 16-bit orders, 2 variants)")
+
     out_path = os.path.join(ROOT, "tests/golden/attention_grad_golden.pt")
     torch.save(grads, out_path)
     print(f"wrote {out_path} ({os.path.getsize(out_path) / 1e6:.2f} MB)")

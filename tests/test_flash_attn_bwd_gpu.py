@@ -217,8 +217,8 @@ def test_bwd_errors_are_the_reference_messages():
     lse = torch.zeros(1, 2, 8, device=DEV)
     with pytest.raises(RuntimeError, match="query and dout must have the same dtype"):
         m.bwd(q.half(), q, q, q, q, lse, None, None, None, None, 0.0, 0.125, False, -1, -1, 0.0, False, None, None)
-    with pytest.raises(RuntimeError, match="does not support dropout"):
-        m.bwd(q, q, q, q, q, lse, None, None, None, None, 0.1, 0.125, False, -1, -1, 0.0, False, None, None)
+    with pytest.raises(RuntimeError, match=r"p_dropout must be in \[0, 1\)"):
+        m.bwd(q, q, q, q, q, lse, None, None, None, None, 1.0, 0.125, False, -1, -1, 0.0, False, None, None)
     with pytest.raises(RuntimeError, match="dq must have shape"):
         m.bwd(q, q, q, q, q, lse, q[:, :4], None, None, None, 0.0, 0.125, False, -1, -1, 0.0, False, None, None)
 

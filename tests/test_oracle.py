@@ -143,3 +143,25 @@ def test_oracle_autograd_reproduces_reference_gradients(name, golden_grads):
             want = gold[f"{nm}_{tag}"].float()
             tol = 2.0 ** -6 * max(1.0, want.abs().max().item())  # a few 16-bit ulps across hosts / the FA3-oracle case
             assert (got.float() - want).abs().max().item() <= tol, (tag, nm)
+
+
+@pytest.mark.parametrize("causal", [False, True])
+def test_oracle_dropout_reproduces_reference(causal, golden_grads):
+    """Dropout branch of the oracle (tests/test_util.py:262-269) against a fixture made by the reference's own
+    attention_ref with the same keep-mask (oracle/make_golden.py): output and gradients, fp32 and 16-bit orders."""
+    gold = golden_grads[f"dropout_pin_causal{int(causal)}"]
+    for tag, extra in (("ref", {}), ("pt", dict(upcast=False, reorder_ops=True))):
+        ql, kl, vl = (gold[n].clone().requires_grad_(True) for n in ("q", "k", "v"))
+        out = oracle.attention_ref(ql, kl, vl, None, None, dropout_p=gold["p_dropout"], dropout_mask=gold["keep"],
+                                   causal=causal, **extra)[0]
+        grads = torch.autograd.grad(out, (ql, kl, vl), gold["g"])
+        for nm, got in zip(("out", "dq", "dk", "dv"), (out.detach(),) + grads):
+            want = gold[f"{nm}_{tag}"].float()
+            tol = 2.0 ** -6 * max(1.0, want.abs().max().item())
+            assert (got.float() - want).abs().max().item() <= tol, (tag, nm)
+    # dropping nothing is the plain softmax; the mask really is applied
+    q, k, v = gold["q"], gold["k"], gold["v"]
+    plain = oracle.attention_ref(q, k, v, causal=causal)[0]
+    all_kept = oracle.attention_ref(q, k, v, dropout_p=0.0, dropout_mask=torch.ones_like(gold["keep"]), causal=causal)[0]
+    assert torch.equal(plain, all_kept)
+    assert not torch.equal(plain, gold["out_ref"])
