@@ -56,7 +56,7 @@ enum fa_status {
     FA_ERR_BAD_HEADS = -4,         /* h % h_k != 0 */
     FA_ERR_BAD_SHAPE = -5,         /* b <= 0, negative lengths, ... */
     FA_ERR_BAD_STRIDE = -6,        /* misaligned rows: strides must keep 16-byte row alignment */
-    FA_ERR_UNSUPPORTED = -7,       /* feature accepted by the ABI but not built (dropout, ...) */
+    FA_ERR_UNSUPPORTED = -7,       /* feature accepted by the ABI but not built for this combination */
     FA_ERR_LAUNCH = -8,            /* hipLaunchKernel failed */
     FA_ERR_BAD_ABI = -9,           /* params->abi_version / struct size mismatch */
     FA_ERR_NO_DEVICE = -10,        /* not a gfx950 device */
