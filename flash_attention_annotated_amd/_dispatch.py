@@ -193,3 +193,27 @@ def kvcache_append(k_new, v_new, k_cache, v_cache, cache_seqlens, cache_batch_id
     st = lib.fa_kvcache_append(ctypes.byref(prm), ctypes.c_void_p(stream))
     if st != 0:
         raise RuntimeError(f"fa_kvcache_append failed ({st}): {_lib.strerror(st)}")
+
+
+_COMBINE_DT = {torch.float16: 0, torch.bfloat16: 1, torch.float32: 3}
+
+
+def combine(out_partial, lse_partial, out, softmax_lse):
+    """fa_fwd_combine (include/fa_fwd.h): out_partial (S, b, s, h, d) fp32, lse_partial (S, b, s, h) fp32 -- any strides
+    with head-dim stride 1; out (b, s, h, d) fp32/fp16/bf16; softmax_lse fp32 indexed (b, s, h) through its strides."""
+    lib = _lib.load()
+    prm = _lib.FaCombineParams()
+    prm.abi_version = _lib.FA_ABI_VERSION
+    prm.struct_size = ctypes.sizeof(prm)
+    prm.out_partial, prm.lse_partial, prm.out, prm.softmax_lse = ptr(out_partial), ptr(lse_partial), ptr(out), ptr(softmax_lse)
+    for i, n in enumerate(("split", "batch", "row", "head")):
+        setattr(prm, f"op_{n}_stride", out_partial.stride(i))
+        setattr(prm, f"lp_{n}_stride", lse_partial.stride(i))
+    for i, n in enumerate(("batch", "row", "head")):
+        setattr(prm, f"o_{n}_stride", out.stride(i))
+        setattr(prm, f"lse_{n}_stride", softmax_lse.stride(i))
+    prm.num_splits, prm.b, prm.seqlen, prm.h, prm.d = out_partial.shape
+    prm.out_dtype = _COMBINE_DT[out.dtype]
+    st = lib.fa_fwd_combine(ctypes.byref(prm), ctypes.c_void_p(torch.cuda.current_stream(out.device).cuda_stream))
+    if st != 0:
+        raise RuntimeError(f"fa_fwd_combine failed ({st}): {_lib.strerror(st)}")

@@ -31,6 +31,8 @@ EXPORTED_SYMBOLS = (
     "fa_kvcache_append_params_size",
     "fa_rotary_apply",
     "fa_rotary_params_size",
+    "fa_fwd_combine",
+    "fa_combine_params_size",
     # include/fa_bwd.h
     "fa_bwd",
     "fa_bwd_validate",
@@ -104,6 +106,20 @@ class FaFwdParams(ctypes.Structure):
         ("rng_state", ctypes.c_void_p),
         ("s_dmask", ctypes.c_void_p),
     ]
+
+
+class FaCombineParams(ctypes.Structure):
+    """Field-for-field mirror of `struct fa_combine_params` (include/fa_fwd.h)."""
+
+    _fields_ = (
+        [("abi_version", ctypes.c_uint32), ("struct_size", ctypes.c_uint32)]
+        + [(n, ctypes.c_void_p) for n in ("out_partial", "lse_partial", "out", "softmax_lse")]
+        + [(f"op_{s}_stride", ctypes.c_int64) for s in ("split", "batch", "row", "head")]
+        + [(f"lp_{s}_stride", ctypes.c_int64) for s in ("split", "batch", "row", "head")]
+        + [(f"o_{s}_stride", ctypes.c_int64) for s in ("batch", "row", "head")]
+        + [(f"lse_{s}_stride", ctypes.c_int64) for s in ("batch", "row", "head")]
+        + [(n, ctypes.c_int32) for n in ("num_splits", "b", "seqlen", "h", "d", "out_dtype")]
+    )
 
 
 class FaKvcacheAppendParams(ctypes.Structure):
@@ -214,6 +230,12 @@ def load():
     lib.fa_rotary_params_size.restype = ctypes.c_uint32
     if lib.fa_rotary_params_size() != ctypes.sizeof(FaRotaryParams):
         raise RuntimeError("fa_rotary_params layout mismatch between include/fa_fwd.h and _lib")
+    lib.fa_fwd_combine.argtypes = [ctypes.POINTER(FaCombineParams), ctypes.c_void_p]
+    lib.fa_fwd_combine.restype = ctypes.c_int
+    lib.fa_combine_params_size.argtypes = []
+    lib.fa_combine_params_size.restype = ctypes.c_uint32
+    if lib.fa_combine_params_size() != ctypes.sizeof(FaCombineParams):
+        raise RuntimeError("fa_combine_params layout mismatch between include/fa_fwd.h and _lib")
     lib.fa_bwd.argtypes = [ctypes.POINTER(FaBwdParams), ctypes.c_void_p]
     lib.fa_bwd.restype = ctypes.c_int
     lib.fa_bwd_validate.argtypes = [ctypes.POINTER(FaBwdParams)]

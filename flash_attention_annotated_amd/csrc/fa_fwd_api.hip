@@ -294,6 +294,57 @@ __global__ void combine_splits_kernel(const T *__restrict__ o_acc, const float *
     }
 }
 
+// ---- fa_fwd_combine: the same merge over caller-provided fp32 partials with arbitrary strides.  One thread = 4
+// consecutive head-dim elements of one (batch, row, head); the work is one pass over out_partial (HBM-bound), the LSE
+// column of a row is re-read by the d/4 threads that share it (L1/L2 hits).
+template <typename TO>
+__device__ __forceinline__ void store_out(TO *dst, float x) { *dst = (TO)x; }
+template <typename TO>
+__global__ void combine_partials_kernel(const fa_combine_params p) {
+    const int chunks = (p.d + 3) >> 2;
+    const int64_t total = (int64_t)p.b * p.seqlen * p.h * chunks;
+    const bool vec = (p.d % 4 == 0) && (p.op_split_stride % 4 == 0) && (p.op_batch_stride % 4 == 0) &&
+                     (p.op_row_stride % 4 == 0) && (p.op_head_stride % 4 == 0) &&
+                     (reinterpret_cast<uintptr_t>(p.out_partial) % 16 == 0);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % chunks);
+        int64_t t = i / chunks;
+        const int hd = (int)(t % p.h);
+        t /= p.h;
+        const int row = (int)(t % p.seqlen);
+        const int bb = (int)(t / p.seqlen);
+        const float *lp = p.lse_partial + bb * p.lp_batch_stride + row * p.lp_row_stride + hd * p.lp_head_stride;
+        const float *op = p.out_partial + bb * p.op_batch_stride + row * p.op_row_stride + hd * p.op_head_stride + c * 4;
+        float mx = -INFINITY;
+        for (int s = 0; s < p.num_splits; ++s) mx = fmaxf(mx, lp[s * p.lp_split_stride]);
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        float wsum = 0.f;
+        const int n = min(4, p.d - c * 4);
+        if (mx != -INFINITY && mx != INFINITY) {
+            for (int s = 0; s < p.num_splits; ++s) {
+                const float l = lp[s * p.lp_split_stride];
+                if (l == -INFINITY) continue;  // (short-circuit: the partial of an empty split is never read)
+                const float w = __expf(l - mx);
+                wsum += w;
+                const float *src = op + s * p.op_split_stride;
+                if (vec) {
+                    const float4 x = *reinterpret_cast<const float4 *>(src);
+                    acc[0] += w * x.x; acc[1] += w * x.y; acc[2] += w * x.z; acc[3] += w * x.w;
+                } else {
+                    for (int j = 0; j < n; ++j) acc[j] += w * src[j];
+                }
+            }
+            const float inv = 1.f / wsum;
+            for (int j = 0; j < 4; ++j) acc[j] *= inv;
+        }
+        TO *dst = reinterpret_cast<TO *>(p.out) + bb * p.o_batch_stride + row * p.o_row_stride + hd * p.o_head_stride + c * 4;
+        for (int j = 0; j < n; ++j) store_out<TO>(dst + j, acc[j]);
+        if (c == 0)
+            p.softmax_lse[bb * p.lse_batch_stride + row * p.lse_row_stride + hd * p.lse_head_stride] =
+                (mx == -INFINITY || mx == INFINITY) ? mx : mx + __logf(wsum);
+    }
+}
+
 int head_dim_tile(int d) {
     if (d <= 64) return 64;
     if (d <= 128) return 128;
@@ -471,6 +522,26 @@ int fa_rotary_apply(const fa_rotary_params *p, void *stream_) {
         hipLaunchKernelGGL(rotary_kernel<_Float16>, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream_), *p);
     else
         hipLaunchKernelGGL(rotary_kernel<__bf16>, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream_), *p);
+    if (hipGetLastError() != hipSuccess) return FA_ERR_LAUNCH;
+    return FA_OK;
+}
+
+uint32_t fa_combine_params_size(void) { return (uint32_t)sizeof(fa_combine_params); }
+
+int fa_fwd_combine(const fa_combine_params *p, void *stream_) {
+    if (!p) return FA_ERR_NULL_POINTER;
+    if (p->abi_version != FA_ABI_VERSION || p->struct_size != sizeof(fa_combine_params)) return FA_ERR_BAD_ABI;
+    if (p->out_dtype != FA_DTYPE_FP32 && p->out_dtype != FA_DTYPE_FP16 && p->out_dtype != FA_DTYPE_BF16) return FA_ERR_BAD_DTYPE;
+    if (p->num_splits <= 0 || p->num_splits > 256) return FA_ERR_BAD_SHAPE;  // "combine only supports num_splits at most 256"
+    if (p->b < 0 || p->seqlen < 0 || p->h <= 0 || p->d <= 0) return FA_ERR_BAD_SHAPE;
+    if (p->b == 0 || p->seqlen == 0) return FA_OK;
+    if (!p->out_partial || !p->lse_partial || !p->out || !p->softmax_lse) return FA_ERR_NULL_POINTER;
+    const int64_t total = (int64_t)p->b * p->seqlen * p->h * ((p->d + 3) / 4);
+    const int blocks = (int)std::min<int64_t>((total + 255) / 256, 256 * 16);
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (p->out_dtype == FA_DTYPE_FP32) hipLaunchKernelGGL(combine_partials_kernel<float>, dim3(blocks), dim3(256), 0, stream, *p);
+    else if (p->out_dtype == FA_DTYPE_FP16) hipLaunchKernelGGL(combine_partials_kernel<_Float16>, dim3(blocks), dim3(256), 0, stream, *p);
+    else hipLaunchKernelGGL(combine_partials_kernel<__bf16>, dim3(blocks), dim3(256), 0, stream, *p);
     if (hipGetLastError() != hipSuccess) return FA_ERR_LAUNCH;
     return FA_OK;
 }

@@ -76,7 +76,38 @@ def _bwd(dout, q, k, v, out, softmax_lse, dq=None, dk=None, dv=None, cu_seqlens_
 
 
 def _fwd_combine(out_partial, lse_partial, out=None, out_dtype=None):
-    raise RuntimeError("flash_attn_3::fwd_combine is not built: split results are merged inside fa_fwd (num_splits)")
+    """mha_combine, hopper/flash_api.cpp:1569-1670: merge caller-held split-KV partials.  out_partial
+    (num_splits, b, seqlen, h, d) fp32, lse_partial (num_splits, b, seqlen, h) fp32 -> (out, softmax_lse (b, seqlen, h))."""
+    def check(cond, msg):
+        if not cond:
+            raise RuntimeError(msg)
+    check(out_partial.dtype == torch.float32, "Attention combine function only support fp32 data type")
+    check(lse_partial.dtype == torch.float32, "Attention combine function only support fp32 data type")
+    check(out_partial.is_cuda and lse_partial.is_cuda, "out_partial must be on CUDA")
+    check(out_partial.stride(-1) == 1, "Input tensor must have contiguous last dimension")
+    check(lse_partial.stride(-2) == 1, "LSE tensor must be contiguous in the seqlen dimension")
+    check(out_partial.dim() == 5, "out_partial must have shape (num_splits, batch_size, seqlen, num_heads, head_size)")
+    num_splits, batch_size, seqlen, num_heads, head_size = out_partial.shape
+    check(num_splits <= 256, "FlashAttention combine only supports num_splits at most 256")
+    check(tuple(lse_partial.shape) == (num_splits, batch_size, seqlen, num_heads),
+          "lse_partial must have shape (num_splits, batch_size, seqlen, num_heads)")
+    out_type = out_dtype if out_dtype is not None else out_partial.dtype
+    check(out_type in (torch.float32, torch.float16, torch.bfloat16), "Output type must be FP32, FP16 or BF16")
+    if out is not None:
+        check(out.dtype == out_type, "out must have the requested output type")
+        check(out.is_cuda, "out must be on CUDA")
+        check(out.stride(-1) == 1, "Output tensor must have contiguous last dimension")
+        check(tuple(out.shape) == (batch_size, seqlen, num_heads, head_size),
+              "out must have shape (batch_size, seqlen, num_heads, head_size)")
+    else:
+        out = torch.empty((batch_size, seqlen, num_heads, head_size), dtype=out_type, device=out_partial.device)
+    with torch.cuda.device(out_partial.device):
+        softmax_lse = torch.empty((batch_size, num_heads, seqlen), dtype=torch.float32,
+                                  device=out_partial.device).transpose(1, 2)  # (:1632)
+        if seqlen > 0 and batch_size > 0:
+            from . import _dispatch
+            _dispatch.combine(out_partial, lse_partial, out, softmax_lse)
+    return out, softmax_lse
 
 
 def _get_scheduler_metadata(batch_size, max_seqlen_q, max_seqlen_k, num_heads, num_heads_k, headdim, headdim_v, qkv_dtype,

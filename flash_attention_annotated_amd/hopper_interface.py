@@ -57,3 +57,8 @@ def flash_attn_varlen_func(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, ma
         window_size=window_size, attention_chunk=attention_chunk, softcap=softcap, num_splits=num_splits,
         pack_gqa=pack_gqa, sm_margin=sm_margin)
     return (out, softmax_lse) if return_attn_probs else out
+
+
+def flash_attn_combine(out_partial, lse_partial, out=None, out_dtype=None):
+    """reference hopper/flash_attn_interface.py:636-637"""
+    return torch.ops.flash_attn_3.fwd_combine(out_partial, lse_partial, out, out_dtype)

@@ -44,7 +44,8 @@ extern "C" {
 enum fa_dtype {
     FA_DTYPE_FP16 = 0,
     FA_DTYPE_BF16 = 1,
-    FA_DTYPE_FP8_E4M3 = 2 /* OCP e4m3fn; hopper/flash_api.cpp:714-722 */
+    FA_DTYPE_FP8_E4M3 = 2, /* OCP e4m3fn; hopper/flash_api.cpp:714-722 */
+    FA_DTYPE_FP32 = 3      /* output type of fa_fwd_combine only */
 };
 
 /* status codes: 0 ok, negative = rejected before launch, nothing was written */
@@ -257,6 +258,30 @@ typedef struct fa_rotary_params {
 
 int fa_rotary_apply(const fa_rotary_params *params, void *stream);
 uint32_t fa_rotary_params_size(void);
+
+/* Merge of split-KV partial results given by the caller: mha_combine / flash_attn_3::fwd_combine
+ * (hopper/flash_api.cpp:1569-1670, hopper/flash_fwd_combine_kernel.h).
+ *   lse[b, i, h] = log sum_s exp(lse_partial[s, b, i, h]);   out[b, i, h, :] = sum_s exp(lse_partial[s] - lse) out_partial[s]
+ * A split with lse_partial = -inf carries no weight; rows where every split is -inf give out = 0, lse = -inf
+ * (attention_combine_ref, hopper/test_flash_attn.py:1105-1114).  Partials are fp32 with arbitrary element strides
+ * (head-dim stride 1); out is fp32 / fp16 / bf16.  num_splits <= 256 like the reference. */
+typedef struct fa_combine_params {
+    uint32_t abi_version; /* FA_ABI_VERSION */
+    uint32_t struct_size; /* sizeof(fa_combine_params) */
+    const float *out_partial; /* (num_splits, b, seqlen, h, d) */
+    const float *lse_partial; /* (num_splits, b, seqlen, h) */
+    void *out;                /* (b, seqlen, h, d) of out_dtype */
+    float *softmax_lse;       /* (b, seqlen, h) through the strides below */
+    int64_t op_split_stride, op_batch_stride, op_row_stride, op_head_stride;
+    int64_t lp_split_stride, lp_batch_stride, lp_row_stride, lp_head_stride;
+    int64_t o_batch_stride, o_row_stride, o_head_stride;
+    int64_t lse_batch_stride, lse_row_stride, lse_head_stride;
+    int32_t num_splits, b, seqlen, h, d;
+    int32_t out_dtype; /* FA_DTYPE_FP32 / FA_DTYPE_FP16 / FA_DTYPE_BF16 */
+} fa_combine_params;
+
+int fa_fwd_combine(const fa_combine_params *params, void *stream);
+uint32_t fa_combine_params_size(void);
 
 /* Test hook: overrides the default kernel variant process-wide (0 = default). */
 void fa_set_default_variant(int32_t variant);

@@ -186,3 +186,13 @@ def sdpa_cpu(q, k, v, causal=False):
         v = v.repeat_interleave(g, dim=2)
     o = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), is_causal=causal)
     return o.transpose(1, 2)
+
+
+def attention_combine_ref(out_partial, lse_partial):
+    """Merge of split-KV partials (hopper/test_flash_attn.py:1105-1114).
+    out_partial: (num_splits, b, seqlen, h, d); lse_partial: (num_splits, b, seqlen, h) -> out (b, seqlen, h, d), lse."""
+    lse = torch.logsumexp(lse_partial, dim=0)
+    scale = torch.exp(lse_partial - lse)
+    scale = torch.where(torch.isinf(scale) | torch.isnan(scale), torch.zeros_like(scale), scale)
+    out = (scale.unsqueeze(-1) * out_partial).sum(0)
+    return out, lse

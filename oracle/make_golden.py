@@ -231,6 +231,25 @@ def main():
         }
         errs = [(pt[i].float() - ref[i].float()).abs().max().item() for i in (1, 2, 3)]
         print(f"{name:34s} |d*_pt - d*_ref| = {errs[0]:.2e} {errs[1]:.2e} {errs[2]:.2e}")
+    # ---- split-KV merge (hopper/test_flash_attn.py:1105-1114, a module that needs the GPU extension at import: the
+    #      one function is compiled out of the syntax tree like attn_bias_from_alibi_slopes) ------------------------
+    import ast
+    path = os.path.join(REF, "hopper/test_flash_attn.py")
+    tree = ast.parse(open(path).read(), filename=path)
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "attention_combine_ref"]
+    ns = {"torch": torch}
+    exec(compile(ast.Module(body=fn, type_ignores=[]), path, "exec"), ns)
+    gen = torch.Generator().manual_seed(31)
+    op = torch.randn(5, 3, 17, 4, 40, generator=gen)
+    lp = torch.randn(5, 3, 17, 4, generator=gen)
+    lp[2:, :1] = -float("inf")
+    lp[:, 2, 3] = -float("inf")  # a row no split saw
+    want_o, want_l = ns["attention_combine_ref"](op, lp)
+    got_o, got_l = mine.attention_combine_ref(op, lp)
+    assert torch.equal(want_o, got_o) and torch.equal(want_l, got_l)
+    grads["combine_pin"] = {"out_partial": op, "lse_partial": lp, "out": want_o, "lse": want_l}
+    print("attention_combine_ref restatement == reference")
+
     # ---- dropout (tests/test_util.py:262-269): with the SAME keep-mask the restatement equals the reference, output
     #      and gradients; the case is kept as a fixture (mask included) for tests/test_oracle.py --------------------
     gen = torch.Generator().manual_seed(4242)

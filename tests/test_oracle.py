@@ -165,3 +165,15 @@ def test_oracle_dropout_reproduces_reference(causal, golden_grads):
     all_kept = oracle.attention_ref(q, k, v, dropout_p=0.0, dropout_mask=torch.ones_like(gold["keep"]), causal=causal)[0]
     assert torch.equal(plain, all_kept)
     assert not torch.equal(plain, gold["out_ref"])
+
+
+def test_oracle_combine_reproduces_reference(golden_grads):
+    """Split-KV merge restatement against the fixture made by the reference's attention_combine_ref
+    (hopper/test_flash_attn.py:1105-1114), -inf splits and an all -inf row included."""
+    gold = golden_grads["combine_pin"]
+    out, lse = oracle.attention_combine_ref(gold["out_partial"], gold["lse_partial"])
+    assert torch.allclose(out, gold["out"], atol=1e-6, rtol=1e-6)
+    assert torch.equal(torch.isinf(lse), torch.isinf(gold["lse"]))
+    fin = ~torch.isinf(lse)
+    assert torch.allclose(lse[fin], gold["lse"][fin], atol=1e-6, rtol=1e-6)
+    assert (out[2, 3] == 0).all() and torch.isinf(lse[2, 3]).all()
