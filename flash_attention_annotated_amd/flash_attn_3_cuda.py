@@ -4,9 +4,12 @@ callable `hopper/flash_attn_interface.py:66` invokes — 34 positional arguments
 
 Built: fp16 / bf16 / fp8 e4m3 inputs (fp8 -> bf16 output, :859), per-(batch, kv head) q/k/v descales (:1115-1146),
 dense and varlen (`cu_seqlens_*`, `seqused_*`), causal / sliding window / softcap, GQA.
-Accepted and rejected by message, like the reference does for compiled-out features (:1148-1165): k_new/v_new
-(append KV), qv, page_table, kv_batch_idx, leftpad_k, rotary_*, attention_chunk.  `scheduler_metadata`, `num_splits`,
-`pack_gqa`, `sm_margin` are performance hints and do not change results: ignored.
+KV-cache arguments (dense q, 16-bit): k_new/v_new (in-place append at seqused_k), page_table (page size % 256 == 0),
+kv_batch_idx, leftpad_k, rotary_cos/sin (+ interleaved), num_splits -- served by the same routines as the FA2
+`fwd_kvcache` surface (flash_attn_2_cuda.fwd_kvcache).
+Accepted and rejected by message, like the reference does for compiled-out features (:1148-1165): qv,
+attention_chunk, cu_seqlens_k_new, seqlens_rotary, KV-cache arguments together with cu_seqlens_q or fp8.
+`scheduler_metadata`, `pack_gqa`, `sm_margin` are performance hints and do not change results: ignored.
 """
 import math
 from typing import Optional
@@ -35,12 +38,27 @@ def fwd(q, k, v, k_new, v_new, qv, out, cu_seqlens_q, cu_seqlens_k, cu_seqlens_k
     for t, n in ((q, "q"), (k, "k"), (v, "v")):
         _check(t.is_cuda, f"{n} must be on CUDA")
         _check(t.stride(-1) == 1, "Input tensor must have contiguous last dimension")
-    for x, n in ((k_new, "k_new"), (v_new, "v_new"), (qv, "qv"), (page_table, "page_table"),
-                 (kv_batch_idx, "kv_batch_idx"), (leftpad_k, "leftpad_k"), (rotary_cos, "rotary_cos"),
-                 (rotary_sin, "rotary_sin"), (seqlens_rotary, "seqlens_rotary"), (cu_seqlens_k_new, "cu_seqlens_k_new")):
+    for x, n in ((qv, "qv"), (seqlens_rotary, "seqlens_rotary"), (cu_seqlens_k_new, "cu_seqlens_k_new")):
         _check(x is None, f"This flash attention build does not support {n}.")
     _check(not attention_chunk, "This flash attention build does not support attention_chunk.")
     is_fp8 = _FP8 is not None and q.dtype == _FP8
+    if any(x is not None for x in (k_new, v_new, page_table, kv_batch_idx, leftpad_k, rotary_cos, rotary_sin)):
+        # KV-cache step (hopper/flash_api.cpp:736-760, 935-1060): k / v are the cache, seqused_k its fill levels
+        _check(cu_seqlens_q is None and cu_seqlens_k is None and seqused_q is None,
+               "This flash attention build does not support KV-cache arguments together with cu_seqlens / seqused_q.")
+        _check(not is_fp8, "This flash attention build does not support KV-cache arguments with fp8 inputs.")
+        _check((k_new is None) == (v_new is None), "k_new and v_new must be passed together")
+        _check((rotary_cos is None) == (rotary_sin is None), "rotary_cos and rotary_sin must be passed together")
+        if k_new is not None or leftpad_k is not None:
+            _check(seqused_k is not None, "seqused_k must be provided with k_new / leftpad_k")
+        if softmax_scale is None:
+            softmax_scale = q.shape[-1] ** (-0.5)
+        from . import flash_attn_2_cuda
+        o, lse = flash_attn_2_cuda.fwd_kvcache(q, k, v, k_new, v_new, seqused_k, rotary_cos, rotary_sin, kv_batch_idx,
+                                               leftpad_k, page_table, None, out, softmax_scale, bool(is_causal),
+                                               int(window_size_left), int(window_size_right), float(softcap),
+                                               bool(is_rotary_interleaved), int(num_splits))
+        return o, lse, None, None
     varlen_q = cu_seqlens_q is not None
     varlen_k = cu_seqlens_k is not None
     _check(varlen_q == varlen_k, "This flash attention build needs cu_seqlens_q and cu_seqlens_k together.")
@@ -105,12 +123,18 @@ def fwd(q, k, v, k_new, v_new, qv, out, cu_seqlens_q, cu_seqlens_k, cu_seqlens_k
 
 
 def bwd(*args, **kwargs):
-    raise RuntimeError("flash_attn_3.bwd: the backward pass is not built in this forward-only back-end")
+    """flash_attn_3::bwd (hopper/flash_api.cpp:1259-1570): see flash_attn_3_ops._bwd."""
+    from . import flash_attn_3_ops  # noqa: F401
+    return torch.ops.flash_attn_3.bwd(*args, **kwargs)
 
 
-def fwd_combine(*args, **kwargs):
-    raise RuntimeError("flash_attn_3.fwd_combine: split-KV is not built in this back-end")
+def fwd_combine(out_partial, lse_partial, out=None, out_dtype=None):
+    """flash_attn_3::fwd_combine (hopper/flash_api.cpp:1569-1670): see flash_attn_3_ops._fwd_combine."""
+    from . import flash_attn_3_ops  # noqa: F401
+    return torch.ops.flash_attn_3.fwd_combine(out_partial, lse_partial, out, out_dtype)
 
 
 def get_scheduler_metadata(*args, **kwargs):
-    raise RuntimeError("flash_attn_3.get_scheduler_metadata: not built (tile scheduling is done inside the kernel)")
+    """flash_attn_3::get_scheduler_metadata: opaque and empty in this build (tiles are scheduled inside the kernel)."""
+    from . import flash_attn_3_ops  # noqa: F401
+    return torch.ops.flash_attn_3.get_scheduler_metadata(*args, **kwargs)

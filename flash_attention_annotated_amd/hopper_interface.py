@@ -62,3 +62,26 @@ def flash_attn_varlen_func(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, ma
 def flash_attn_combine(out_partial, lse_partial, out=None, out_dtype=None):
     """reference hopper/flash_attn_interface.py:636-637"""
     return torch.ops.flash_attn_3.fwd_combine(out_partial, lse_partial, out, out_dtype)
+
+
+def flash_attn_with_kvcache(q, k_cache, v_cache, k=None, v=None, qv=None, rotary_cos=None, rotary_sin=None,
+                            cache_seqlens=None, cache_batch_idx=None, cache_leftpad=None, page_table=None,
+                            cu_seqlens_q=None, cu_seqlens_k_new=None, max_seqlen_q=None, rotary_seqlens=None,
+                            q_descale=None, k_descale=None, v_descale=None, softmax_scale=None, causal=False,
+                            window_size=(-1, -1), attention_chunk=0, softcap=0.0, rotary_interleaved=True,
+                            scheduler_metadata=None, num_splits=0, pack_gqa=None, sm_margin=0, return_softmax_lse=False):
+    """reference hopper/flash_attn_interface.py:640-800: attention over a KV cache, optionally appending k / v in place
+    (rotated by rotary_cos / rotary_sin) first.  Paged caches need page sizes that are multiples of 256 here."""
+    assert k_cache.stride(-1) == 1, "k_cache must have contiguous last dimension"
+    assert v_cache.stride(-1) == 1, "v_cache must have contiguous last dimension"
+    if softmax_scale is None:
+        softmax_scale = (q.shape[-1] + (qv.shape[-1] if qv is not None else 0)) ** (-0.5)
+    if cache_seqlens is not None and isinstance(cache_seqlens, int):
+        cache_seqlens = torch.full((q.shape[0],), cache_seqlens, dtype=torch.int32, device=k_cache.device)
+    out, softmax_lse, *rest = _flash_attn_forward(
+        q, k_cache, v_cache, k, v, qv, None, cu_seqlens_q, None, cu_seqlens_k_new, None, cache_seqlens, max_seqlen_q, None,
+        page_table, cache_batch_idx, cache_leftpad, rotary_cos, rotary_sin, rotary_seqlens, q_descale, k_descale, v_descale,
+        softmax_scale, causal=causal, window_size=window_size, attention_chunk=attention_chunk, softcap=softcap,
+        rotary_interleaved=rotary_interleaved, scheduler_metadata=scheduler_metadata, num_splits=num_splits,
+        pack_gqa=pack_gqa, sm_margin=sm_margin)
+    return (out, softmax_lse, *rest) if return_softmax_lse else out

@@ -1,0 +1,121 @@
+"""GPU tests of the FA3 KV-cache surface (hopper/flash_attn_interface.py:640-800 `flash_attn_with_kvcache`, i.e.
+flash_attn_3::fwd with k_new / page_table / kv_batch_idx / leftpad_k / rotary arguments).
+
+The FA3 entry point is served by the same routines as the FA2 `fwd_kvcache` surface, whose parity against the oracle is
+tests/test_kvcache_gpu.py; here: the FA3 call against the oracle for the basic cases (tolerance
+|out - ref| <= 3 |pt - ref| + 1e-5, hopper/test_flash_attn.py:1001-1010) and bit-equality (output, LSE, mutated cache)
+with the FA2 call for every argument combination.
+"""
+import pytest
+import torch
+
+from oracle import attention_ref as oracle
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _fa3():
+    from flash_attention_annotated_amd import hopper_interface
+    return hopper_interface
+
+
+def _fa2():
+    import flash_attention_annotated_amd as fa
+    return fa
+
+
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("new_kv", [False, True])
+@pytest.mark.parametrize("sq,sk,d", [(1, 700, 128), (5, 512, 64)])
+def test_fa3_kvcache_against_oracle(sq, sk, d, new_kv, causal):
+    torch.manual_seed(sq + sk)
+    b, h, hk = 3, 4, 2
+    q = torch.randn(b, sq, h, d, dtype=torch.bfloat16)
+    kc = torch.randn(b, sk, hk, d, dtype=torch.bfloat16)
+    vc = torch.randn(b, sk, hk, d, dtype=torch.bfloat16)
+    lens = torch.randint(1, sk - sq, (b,), dtype=torch.int32)
+    k = torch.randn(b, sq, hk, d, dtype=torch.bfloat16) if new_kv else None
+    v = torch.randn(b, sq, hk, d, dtype=torch.bfloat16) if new_kv else None
+    kc_ref, vc_ref = kc.clone(), vc.clone()
+    total = lens.clone()
+    if new_kv:
+        for i in range(b):
+            kc_ref[i, lens[i]:lens[i] + sq] = k[i]
+            vc_ref[i, lens[i]:lens[i] + sq] = v[i]
+        total = lens + sq
+    kmask = torch.arange(sk).view(1, -1) < total.view(-1, 1)
+    ref = oracle.attention_ref(q, kc_ref, vc_ref, None, kmask, causal=causal)[0]
+    pt = oracle.attention_ref(q, kc_ref, vc_ref, None, kmask, causal=causal, upcast=False, reorder_ops=True)[0]
+    kc_d, vc_d = kc.to(DEV), vc.to(DEV)
+    out, lse, *_ = _fa3().flash_attn_with_kvcache(q.to(DEV), kc_d, vc_d, None if k is None else k.to(DEV),
+                                                 None if v is None else v.to(DEV), cache_seqlens=lens.to(DEV),
+                                                 causal=causal, return_softmax_lse=True)
+    err = (out.float().cpu() - ref.float()).abs().max().item()
+    assert err <= 3 * (pt.float() - ref.float()).abs().max().item() + 1e-5
+    assert tuple(lse.shape) == (b, h, sq)
+    assert torch.equal(kc_d.cpu(), kc_ref) and torch.equal(vc_d.cpu(), vc_ref)
+
+
+@pytest.mark.parametrize("feature", ["batch_idx", "paged", "rotary", "rotary_interleaved", "leftpad", "splits", "int_seqlens",
+                                     "local_softcap"])
+def test_fa3_kvcache_equals_fa2_surface(feature):
+    torch.manual_seed(17)
+    b, sq, sk, h, hk, d = 3, 4, 1024, 8, 2, 128
+    q = torch.randn(b, sq, h, d, dtype=torch.float16, device=DEV)
+    k = torch.randn(b, sq, hk, d, dtype=torch.float16, device=DEV)
+    v = torch.randn(b, sq, hk, d, dtype=torch.float16, device=DEV)
+    lens = torch.tensor([100, 517, 1000], dtype=torch.int32, device=DEV)
+    kw3, kw2 = {}, {}
+    bc = b
+    if feature == "batch_idx":
+        bc = 5
+        idx = torch.tensor([4, 0, 2], dtype=torch.int32, device=DEV)
+        kw3["cache_batch_idx"] = kw2["cache_batch_idx"] = idx
+    kc = torch.randn(bc, sk, hk, d, dtype=torch.float16, device=DEV)
+    vc = torch.randn(bc, sk, hk, d, dtype=torch.float16, device=DEV)
+    if feature == "paged":
+        table = torch.randperm(b * 4, dtype=torch.int32, device=DEV).view(b, 4)
+        kc, vc = (x.reshape(b * 4, 256, hk, d).contiguous() for x in (kc, vc))
+        kw3["page_table"] = kw2["block_table"] = table
+    if feature.startswith("rotary"):
+        ang = torch.rand(sk, d // 4, device=DEV) * 6.28
+        il = feature == "rotary_interleaved"
+        kw3.update(rotary_cos=torch.cos(ang).half(), rotary_sin=torch.sin(ang).half(), rotary_interleaved=il)
+        kw2.update(rotary_cos=torch.cos(ang).half(), rotary_sin=torch.sin(ang).half(), rotary_interleaved=il)
+    if feature == "leftpad":
+        lp = torch.tensor([0, 64, 130], dtype=torch.int32, device=DEV)
+        kw3["cache_leftpad"] = kw2["cache_leftpad"] = lp
+    if feature == "splits":
+        kw3["num_splits"] = kw2["num_splits"] = 4
+    if feature == "local_softcap":
+        kw3.update(window_size=(200, 0), softcap=20.0)
+        kw2.update(window_size=(200, 0), softcap=20.0)
+    seqlens = 300 if feature == "int_seqlens" else lens
+    if "num_splits" not in kw3:
+        kw3["num_splits"] = kw2["num_splits"] = 1
+    kc3, vc3, kc2, vc2 = kc.clone(), vc.clone(), kc.clone(), vc.clone()
+    o3, lse3, *_ = _fa3().flash_attn_with_kvcache(q, kc3, vc3, k, v, cache_seqlens=seqlens, causal=True,
+                                                 return_softmax_lse=True, **kw3)
+    o2, lse2 = _fa2().flash_attn_with_kvcache(q, kc2, vc2, k, v, cache_seqlens=seqlens, causal=True,
+                                              return_softmax_lse=True, **kw2)
+    assert torch.equal(o3, o2) and torch.equal(lse3, lse2)
+    assert torch.equal(kc3, kc2) and torch.equal(vc3, vc2)
+    assert not torch.equal(kc3, kc)  # the append happened
+
+
+def test_fa3_kvcache_rejections():
+    fa3 = _fa3()
+    q = torch.randn(2, 1, 4, 64, dtype=torch.bfloat16, device=DEV)
+    kc = torch.randn(2, 256, 4, 64, dtype=torch.bfloat16, device=DEV)
+    lens = torch.tensor([5, 9], dtype=torch.int32, device=DEV)
+    with pytest.raises(RuntimeError, match="does not support seqlens_rotary"):
+        fa3.flash_attn_with_kvcache(q, kc, kc, cache_seqlens=lens, rotary_seqlens=lens)
+    with pytest.raises(RuntimeError, match="does not support cu_seqlens_k_new"):
+        fa3.flash_attn_with_kvcache(q, kc, kc, cache_seqlens=lens, cu_seqlens_k_new=lens)
+    with pytest.raises(RuntimeError, match="k_new and v_new must be passed together"):
+        fa3.flash_attn_with_kvcache(q, kc, kc, k=q, cache_seqlens=lens)
+    pages = torch.randn(8, 64, 4, 64, dtype=torch.bfloat16, device=DEV)  # page size 64: not a multiple of 256
+    with pytest.raises(RuntimeError, match="divisible by 256"):
+        fa3.flash_attn_with_kvcache(q, pages, pages, cache_seqlens=lens,
+                                    page_table=torch.zeros(2, 4, dtype=torch.int32, device=DEV))
