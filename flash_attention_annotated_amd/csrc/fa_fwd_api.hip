@@ -615,7 +615,7 @@ int fa_fwd_validate(const fa_fwd_params *p) {
     if (p->leftpad_k && (p->block_table || fp8)) return FA_ERR_UNSUPPORTED;  // (:1396 "Paged KV and leftpad_k" not together)
     if (p->block_table) {
         if (fp8 || p->kv_batch_idx) return FA_ERR_UNSUPPORTED;  // "Paged KVcache does not support cache_batch_idx" (:1247)
-        if (p->page_block_size <= 0 || p->page_block_size % 256 != 0) return FA_ERR_BAD_SHAPE;  // (:1265)
+        if (p->page_block_size <= 0) return FA_ERR_BAD_SHAPE;  // any size (the FA2 entry point keeps its % 256 rule in Python)
         if (p->block_table_batch_stride < 0 || p->block_table_batch_stride > 0x7fffffff) return FA_ERR_BAD_STRIDE;
     }
     return FA_OK;

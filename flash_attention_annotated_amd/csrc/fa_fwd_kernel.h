@@ -66,7 +66,7 @@ struct KParams {
     int32_t alibi_bs;      // batch stride of alibi (0 for the (h) form)
     const int32_t *kv_batch_idx;  // KV-cache decode: cache entry of each batch row (NULL = identity), dense only
     const int32_t *block_table;   // paged KV: page of key row j of batch i = block_table[i * bt_bs + j / page_size]
-    int32_t bt_bs, page_size;     // (only the fwd_kernel shape reads paged caches: its tiles are 64-key aligned)
+    int32_t bt_bs, page_size;     // (only the fwd_kernel shape reads paged caches; any page size, see load_tile)
     // split-KV: workgroup id = split * grid + (id inside one split's grid); split s handles the s-th part of the key
     // blocks of its tile and writes a normalised partial O / LSE at o + s * o_split_stride, lse + s * lse_split_stride
     int32_t num_splits;
@@ -354,12 +354,25 @@ __global__ __launch_bounds__(NWAVES * 64, (D <= 128 ? 2 : 1)) void fwd_kernel(co
         const int k0 = n * BLOCK_N;
         const T *kt = kp + (int64_t)k0 * p.k_row_stride;  // scalar
         const T *vt = vp + (int64_t)k0 * p.v_row_stride;
-        if (pages) {  // a 64-key tile lies inside one page (page_size % 256 == 0)
-            const int page = pages[k0 / p.page_size], in_page = k0 % p.page_size;
-            kt = kp + (int64_t)page * p.k_batch_stride + (int64_t)in_page * p.k_row_stride;
-            vt = vp + (int64_t)page * p.v_batch_stride + (int64_t)in_page * p.v_row_stride;
-        }
         const int last = sk - 1 - k0;                     // >= 0 for every tile in [n_min, n_max)
+        if (pages) {
+            if (p.page_size % BLOCK_N == 0) {  // a 64-key tile lies inside one page
+                const int page = pages[k0 / p.page_size], in_page = k0 % p.page_size;
+                kt = kp + (int64_t)page * p.k_batch_stride + (int64_t)in_page * p.k_row_stride;
+                vt = vp + (int64_t)page * p.v_batch_stride + (int64_t)in_page * p.v_row_stride;
+            } else {  // any other page size (FA3: "page_block_size can be arbitrary"): the page is looked up per row
+#pragma unroll
+                for (int i = 0; i < LD_PER_THREAD; ++i) {
+                    const int row = k0 + min(ld_row[i], last);
+                    const int pi = row / p.page_size;
+                    const int64_t page = pages[pi];
+                    const int in_page = row - pi * p.page_size;
+                    kreg[i] = *(const u32x4 *)(kp + page * p.k_batch_stride + (int64_t)in_page * p.k_row_stride + ld_col[i]);
+                    vreg[i] = *(const u32x4 *)(vp + page * p.v_batch_stride + (int64_t)in_page * p.v_row_stride + ld_col[i]);
+                }
+                return;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < LD_PER_THREAD; ++i) {
             const int row = min(ld_row[i], last);

@@ -84,14 +84,16 @@ def _check_leftpad(leftpad_k_, batch_size, paged):
     _check_shape(leftpad_k_, "leftpad_k", batch_size)
 
 
-def _check_block_table(block_table_, kcache, batch_size):
+def _check_block_table(block_table_, kcache, batch_size, page_multiple=256):
     """Paged KV (csrc/flash_attn/flash_api.cpp:554-560, 1245-1266): returns (page_block_size, max_num_blocks_per_seq)."""
     _check_device(block_table_, "block_table")
     _check(block_table_.dtype == torch.int32, "block_table must have dtype torch.int32")
     _check(block_table_.stride(-1) == 1, "block_table must have contiguous last dimension")
     _check(kcache.dim() == 4, "paged k/v must have shape (num_blocks, page_block_size, num_heads_k, head_size)")
     page_block_size = kcache.shape[1]
-    _check(page_block_size % 256 == 0, "Paged KV cache block size must be divisible by 256")
+    # the FA2 entry points keep the reference's rule (:1265); the FA3 surface ("page_block_size can be arbitrary",
+    # hopper/flash_attn_interface.py:712) passes page_multiple=1 -- the kernel reads any page size
+    _check(page_block_size % page_multiple == 0, f"Paged KV cache block size must be divisible by {page_multiple}")
     _check(block_table_.dim() == 2 and block_table_.shape[0] == batch_size,
            "block_table must have shape (batch_size, max_num_blocks_per_seq)")
     return page_block_size, block_table_.shape[1]
@@ -426,6 +428,20 @@ def fwd_kvcache(q: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor, k_:
                 alibi_slopes_: Optional[torch.Tensor], out_: Optional[torch.Tensor], softmax_scale: float,
                 is_causal: bool, window_size_left: int, window_size_right: int, softcap: float,
                 is_rotary_interleaved: bool, num_splits: int) -> List[torch.Tensor]:
+    """mha_fwd_kvcache, csrc/flash_attn/flash_api.cpp:1202-1476 (20 positional arguments).  Returns [out, softmax_lse]; see
+    _fwd_kvcache_impl.  Paged caches follow the reference's rule here: page size divisible by 256 (:1265)."""
+    return _fwd_kvcache_impl(q, kcache, vcache, k_, v_, seqlens_k_, rotary_cos_, rotary_sin_, cache_batch_idx_, leftpad_k_,
+                             block_table_, alibi_slopes_, out_, softmax_scale, is_causal, window_size_left,
+                             window_size_right, softcap, is_rotary_interleaved, num_splits, 256)
+
+
+def _fwd_kvcache_impl(q: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor, k_: Optional[torch.Tensor],
+                v_: Optional[torch.Tensor], seqlens_k_: Optional[torch.Tensor], rotary_cos_: Optional[torch.Tensor],
+                rotary_sin_: Optional[torch.Tensor], cache_batch_idx_: Optional[torch.Tensor],
+                leftpad_k_: Optional[torch.Tensor], block_table_: Optional[torch.Tensor],
+                alibi_slopes_: Optional[torch.Tensor], out_: Optional[torch.Tensor], softmax_scale: float,
+                is_causal: bool, window_size_left: int, window_size_right: int, softcap: float,
+                is_rotary_interleaved: bool, num_splits: int, _page_multiple: int) -> List[torch.Tensor]:
     """mha_fwd_kvcache, csrc/flash_attn/flash_api.cpp:1202-1476.  Returns [out, softmax_lse].
 
     Built: in-place append of k_/v_ at seqlens_k_ (keys optionally rotated), attention over the first seqlens_k_
@@ -447,7 +463,7 @@ def fwd_kvcache(q: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor, k_:
     batch_size, seqlen_q, num_heads, head_size_og = q.shape
     batch_size_c, seqlen_k, num_heads_k = kcache.shape[0], kcache.shape[1], kcache.shape[2]
     if paged:
-        page_block_size, max_blocks = _check_block_table(block_table_, kcache, batch_size)
+        page_block_size, max_blocks = _check_block_table(block_table_, kcache, batch_size, _page_multiple)
         seqlen_k, batch_size_c = max_blocks * page_block_size, batch_size  # (:1266-1268)
     _check(batch_size > 0, "batch size must be positive")
     _check(head_size_og <= 256, "FlashAttention forward only supports head dimension at most 256")

@@ -4,7 +4,7 @@ callable `hopper/flash_attn_interface.py:66` invokes — 34 positional arguments
 
 Built: fp16 / bf16 / fp8 e4m3 inputs (fp8 -> bf16 output, :859), per-(batch, kv head) q/k/v descales (:1115-1146),
 dense and varlen (`cu_seqlens_*`, `seqused_*`), causal / sliding window / softcap, GQA.
-KV-cache arguments (dense q, 16-bit): k_new/v_new (in-place append at seqused_k), page_table (page size % 256 == 0),
+KV-cache arguments (dense q, 16-bit): k_new/v_new (in-place append at seqused_k), page_table (any page size),
 kv_batch_idx, leftpad_k, rotary_cos/sin (+ interleaved), num_splits -- served by the same routines as the FA2
 `fwd_kvcache` surface (flash_attn_2_cuda.fwd_kvcache).
 Accepted and rejected by message, like the reference does for compiled-out features (:1148-1165): qv,
@@ -54,10 +54,10 @@ def fwd(q, k, v, k_new, v_new, qv, out, cu_seqlens_q, cu_seqlens_k, cu_seqlens_k
         if softmax_scale is None:
             softmax_scale = q.shape[-1] ** (-0.5)
         from . import flash_attn_2_cuda
-        o, lse = flash_attn_2_cuda.fwd_kvcache(q, k, v, k_new, v_new, seqused_k, rotary_cos, rotary_sin, kv_batch_idx,
+        o, lse = flash_attn_2_cuda._fwd_kvcache_impl(q, k, v, k_new, v_new, seqused_k, rotary_cos, rotary_sin, kv_batch_idx,
                                                leftpad_k, page_table, None, out, softmax_scale, bool(is_causal),
                                                int(window_size_left), int(window_size_right), float(softcap),
-                                               bool(is_rotary_interleaved), int(num_splits))
+                                               bool(is_rotary_interleaved), int(num_splits), 1)
         return o, lse, None, None
     varlen_q = cu_seqlens_q is not None
     varlen_k = cu_seqlens_k is not None

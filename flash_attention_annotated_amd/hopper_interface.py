@@ -71,7 +71,7 @@ def flash_attn_with_kvcache(q, k_cache, v_cache, k=None, v=None, qv=None, rotary
                             window_size=(-1, -1), attention_chunk=0, softcap=0.0, rotary_interleaved=True,
                             scheduler_metadata=None, num_splits=0, pack_gqa=None, sm_margin=0, return_softmax_lse=False):
     """reference hopper/flash_attn_interface.py:640-800: attention over a KV cache, optionally appending k / v in place
-    (rotated by rotary_cos / rotary_sin) first.  Paged caches need page sizes that are multiples of 256 here."""
+    (rotated by rotary_cos / rotary_sin) first.  Paged caches: any page size."""
     assert k_cache.stride(-1) == 1, "k_cache must have contiguous last dimension"
     assert v_cache.stride(-1) == 1, "v_cache must have contiguous last dimension"
     if softmax_scale is None:

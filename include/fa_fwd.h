@@ -142,7 +142,7 @@ typedef struct fa_fwd_params {
     /* Paged KV cache (csrc/flash_attn/flash_api.cpp:1245-1266, 538-560; src/flash_fwd_kernel.h:560-576): k and v are
      * (num_blocks, page_block_size, h_k, d) -- k/v_batch_stride is the page stride -- and key row j of batch i lives in
      * page block_table[i * block_table_batch_stride + j / page_block_size], row j % page_block_size.
-     * page_block_size must be a multiple of 256 (so that no 64-key tile straddles two pages).  NULL = contiguous. */
+     * Any page_block_size >= 1 (multiples of 64 take the tile-granular lookup, others a per-row one).  NULL = contiguous. */
     const int32_t *block_table;
     int64_t block_table_batch_stride;
     int32_t page_block_size;
