@@ -156,3 +156,50 @@ def test_flash_attn_3_ops_fwd_and_bwd():
     meta = torch.ops.flash_attn_3.get_scheduler_metadata(2, 150, 180, 4, 2, 64, 64, torch.bfloat16,
                                                           torch.full((2,), 180, dtype=torch.int32, device="cuda"))
     assert meta.dtype == torch.int32
+
+
+def test_fa3_interface_autograd_matches_fa2_surface():
+    """hopper_interface.flash_attn_func / flash_attn_varlen_func / flash_attn_qkvpacked_func are differentiable
+    (hopper/flash_attn_interface.py:157-442); same kernels as the FA2 surface, so gradients are bit-identical to it
+    (whose parity against the oracle is tests/test_flash_attn_bwd_gpu.py)."""
+    import flash_attention_annotated_amd as fa2
+    fa3 = _fa3()
+    torch.manual_seed(5)
+    b, s, h, hk, d = 2, 200, 4, 2, 64
+    q = torch.randn(b, s, h, d, dtype=torch.bfloat16, device=DEV, requires_grad=True)
+    k = torch.randn(b, s, hk, d, dtype=torch.bfloat16, device=DEV, requires_grad=True)
+    v = torch.randn(b, s, hk, d, dtype=torch.bfloat16, device=DEV, requires_grad=True)
+    g = torch.randn(b, s, h, d, dtype=torch.bfloat16, device=DEV)
+    for kw in (dict(causal=True), dict(window_size=(30, 10)), dict(causal=True, softcap=20.0)):
+        o3, lse3 = fa3.flash_attn_func(q, k, v, return_attn_probs=True, **kw)
+        o2 = fa2.flash_attn_func(q, k, v, **kw)
+        assert torch.equal(o3, o2) and not lse3.requires_grad
+        for a, b_ in zip(torch.autograd.grad(o3, (q, k, v), g), torch.autograd.grad(o2, (q, k, v), g)):
+            assert torch.equal(a, b_)
+    # varlen
+    lens = [200, 57]
+    cu = torch.tensor([0, 200, 257], dtype=torch.int32, device=DEV)
+    qu = torch.randn(257, h, d, dtype=torch.float16, device=DEV, requires_grad=True)
+    ku = torch.randn(257, hk, d, dtype=torch.float16, device=DEV, requires_grad=True)
+    vu = torch.randn(257, hk, d, dtype=torch.float16, device=DEV, requires_grad=True)
+    gu = torch.randn(257, h, d, dtype=torch.float16, device=DEV)
+    o3 = fa3.flash_attn_varlen_func(qu, ku, vu, cu, cu, max(lens), max(lens), causal=True)
+    o2 = fa2.flash_attn_varlen_func(qu, ku, vu, cu, cu, max(lens), max(lens), causal=True)
+    assert torch.equal(o3, o2)
+    for a, b_ in zip(torch.autograd.grad(o3, (qu, ku, vu), gu), torch.autograd.grad(o2, (qu, ku, vu), gu)):
+        assert torch.equal(a, b_)
+    # qkv packed: (b, s, 3, h, d) and the GQA form (b, s, h + 2 h_k, d)
+    qkv = torch.randn(b, s, 3, h, d, dtype=torch.bfloat16, device=DEV, requires_grad=True)
+    o3 = fa3.flash_attn_qkvpacked_func(qkv, causal=True)
+    (d3,) = torch.autograd.grad(o3, qkv, g)
+    o2 = fa2.flash_attn_qkvpacked_func(qkv, causal=True)
+    (d2,) = torch.autograd.grad(o2, qkv, g)
+    assert torch.equal(o3, o2) and torch.equal(d3, d2)
+    packed = torch.cat([q, k, v], dim=2).detach().requires_grad_(True)  # (b, s, h + 2 hk, d)
+    o3 = fa3.flash_attn_qkvpacked_func(packed, causal=True, num_heads_q=h)
+    (dp,) = torch.autograd.grad(o3, packed, g)
+    o2 = fa2.flash_attn_func(q, k, v, causal=True)
+    want = torch.cat(torch.autograd.grad(o2, (q, k, v), g), dim=2)
+    assert torch.equal(o3, o2) and torch.equal(dp, want)
+    meta = fa3.get_scheduler_metadata(b, 1, 4096, h, hk, d, torch.full((b,), 100, dtype=torch.int32, device=DEV))
+    assert meta.dtype == torch.int32
