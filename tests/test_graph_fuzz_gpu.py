@@ -169,3 +169,37 @@ def test_random_sweep_against_oracle(chunk):
             assert torch.isfinite(x).all(), (chunk, it, c, name)
             err = (x - r.float()).abs().max().item()
             assert err <= _bound(r, p_, mult), f"chunk {chunk} case {it} {c}: {name} err {err:.3e} > {_bound(r, p_, mult):.3e}"
+
+
+def test_tensors_beyond_2_31_elements():
+    """64-bit addressing at sizes the 288 GB part invites: q / out / dq of 2^31 elements (4 GiB each, b1 s262144 h64 d128,
+    GQA 8:1) under a (2047, 0) window.  Property at full size: the last 1024 query rows, and the gradients they induce,
+    equal the same computation on the sliced tail of the tensors (an offset that wrapped at 32 bits would read other rows)."""
+    fa = _api()
+    torch.manual_seed(9)
+    S, h, hk, d, W, T = 1 << 18, 64, 8, 128, 2047, 1024
+    q = torch.randn(1, S, h, d, device=DEV, dtype=torch.bfloat16)
+    k = torch.randn(1, S, hk, d, device=DEV, dtype=torch.bfloat16)
+    v = torch.randn(1, S, hk, d, device=DEV, dtype=torch.bfloat16)
+    assert q.numel() == 1 << 31
+    g = torch.zeros_like(q)
+    g[:, S - T:] = torch.randn(1, T, h, d, device=DEV, dtype=torch.bfloat16)
+    q.requires_grad_(True); k.requires_grad_(True); v.requires_grad_(True)
+    out = fa.flash_attn_func(q, k, v, window_size=(W, 0))
+    dq, dk, dv = torch.autograd.grad(out, (q, k, v), g)
+    K0 = S - 4096  # every key a tail row can see lies in [S - T - W, S)
+    qs = q[:, S - T:].detach().clone().requires_grad_(True)
+    ks = k[:, K0:].detach().clone().requires_grad_(True)
+    vs = v[:, K0:].detach().clone().requires_grad_(True)
+    out_s = fa.flash_attn_func(qs, ks, vs, window_size=(W, 0))
+    dq_s, dk_s, dv_s = torch.autograd.grad(out_s, (qs, ks, vs), g[:, S - T:].clone())
+    for name, big, small in (("out", out[:, S - T:], out_s), ("dq", dq[:, S - T:], dq_s), ("dk", dk[:, K0:], dk_s),
+                             ("dv", dv[:, K0:], dv_s)):
+        err = (big.float() - small.float()).abs().max().item()
+        scale = small.float().abs().max().item()
+        assert err <= 2.0 ** -6 * max(scale, 1.0), f"{name}: {err:.3e} vs scale {scale:.3e}"
+    # rows / keys that no tail row touches got exactly zero gradient
+    assert not dq[:, : S - T].any() and not dk[:, : S - T - W].any() and not dv[:, : S - T - W].any()
+    # first rows as well (low offsets), against the oracle-checked small path
+    out_h = fa.flash_attn_func(q[:, :512].detach(), k[:, :512].detach(), v[:, :512].detach(), window_size=(W, 0))
+    assert (out[:, :512].float() - out_h.float()).abs().max().item() <= 2.0 ** -6
