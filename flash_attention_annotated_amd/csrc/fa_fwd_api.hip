@@ -215,6 +215,17 @@ int effective_variant(const fa_fwd_params *p) {
     if (variant == 0 || variant == 3) {
         if (p->block_table) variant = 1;
         else if (!p->cu_seqlens_q && p->seqlen_q <= 128) variant = 2;
+        else if (variant == 0) {
+            // Short key ranges: a 256-row workgroup sweeps only a handful of 64-key tiles, so its fixed cost (~13 us) and,
+            // under a causal mask, the idle time of the waves whose rows end early (all four meet at every tile barrier)
+            // outweigh the pipelined loop.  Measured on the reference's benchmark grid (16k tokens, tools/fwd_grid.py):
+            //   d64  causal s512/1024/2048: 178/255/379 -> 235/332/431 TFLOP/s (4 waves x 32 rows); non-causal s512 421 -> 459
+            //   d128 causal s512/1024:      230/345     -> 293/364      TFLOP/s (8 waves x 32 rows)
+            const bool causal_like = p->is_causal || (p->window_size_right == 0 && p->window_size_left < 0);
+            const int tile = head_dim_tile(p->d);
+            if (tile == 64 && ((causal_like && p->seqlen_k <= 2048) || p->seqlen_k <= 512)) variant = 2;
+            else if (tile == 128 && causal_like && p->seqlen_k <= 1024) variant = 1;
+        }
     }
     return variant;
 }
