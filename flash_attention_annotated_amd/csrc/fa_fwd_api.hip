@@ -444,6 +444,14 @@ extern "C" {
 
 uint32_t fa_fwd_params_size(void) { return (uint32_t)sizeof(fa_fwd_params); }
 uint32_t fa_abi_version(void) { return FA_ABI_VERSION; }
+
+#ifdef FA_TIMING
+// developer-only: copy the phase timestamps of the last fwd_kernel_w64 launch (see fa_fwd_kernel_w64.h) to the host
+int fa_debug_read_timing(unsigned long long *dst, int n_wg) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(fa::fa_timing_buf), sizeof(unsigned long long) * 32 * n_wg) == hipSuccess ? 0 : -1;
+}
+#endif
 void fa_set_default_variant(int32_t variant) { g_default_variant.store(variant); }
 
 const char *fa_strerror(int status) {

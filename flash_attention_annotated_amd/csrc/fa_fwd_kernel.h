@@ -316,13 +316,18 @@ __global__ __launch_bounds__(NWAVES * 64, (D <= 128 ? 2 : 1)) void fwd_kernel(co
     const bool wave_active = wrow < sq;
 
     // ---- Q fragments: B operand of S^T = K.Q^T; lane (r,hh) holds Q[row r][16ks + 8hh .. +8] ------
+    // (branch-free loads, zeroed by selects afterwards: predicated loads are waited for one by one -- see fa_fwd_kernel_w64.h)
     u32x4 qf[KSTEPS];
+    {
+        const T *qr = qp + (int64_t)min(my_row, sq - 1) * p.q_row_stride;
 #pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) {
-        const int d0 = ks * 16 + hh * 8;
-        u32x4 val = {0, 0, 0, 0};
-        if (my_row < sq && d0 < p.d) val = *(const u32x4 *)(qp + (int64_t)my_row * p.q_row_stride + d0);
-        qf[ks] = val;
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const int d0 = ks * 16 + hh * 8;
+            qf[ks] = *(const u32x4 *)(qr + (d0 < p.d ? d0 : 0));
+        }
+        const u32x4 z4 = {0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) qf[ks] = (ks * 16 + hh * 8 < p.d && my_row < sq) ? qf[ks] : z4;
     }
 
     // ---- accumulators --------------------------------------------------------------------------
@@ -574,14 +579,20 @@ __global__ __launch_bounds__(NWAVES * 64, (D <= 128 ? 2 : 1)) void fwd_kernel(co
     __syncthreads();
     if (wave_active) {
         const char *obuf = smem + wave * (32 * O_ROW_BYTES);
+        // (LDS reads outside the predicate: all of them are issued before the first store; inside it each read is
+        //  waited for in its own exec-masked block -- 16 serial LDS round trips at D = 128)
+        constexpr int NCH = (32 * CH_PER_ROW) / 64;
+        u32x4 val[NCH];
 #pragma unroll
-        for (int i = 0; i < (32 * CH_PER_ROW) / 64; ++i) {
+        for (int i = 0; i < NCH; ++i) {
+            const int c = lane + i * 64;
+            val[i] = *(const u32x4 *)(obuf + (c / CH_PER_ROW) * O_ROW_BYTES + (c % CH_PER_ROW) * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
             const int c = lane + i * 64;
             const int row = c / CH_PER_ROW, ch = c % CH_PER_ROW;
-            if (wrow + row < sq && ch * 8 < p.d) {
-                const u32x4 val = *(const u32x4 *)(obuf + row * O_ROW_BYTES + ch * 16);
-                *(u32x4 *)(op + (int64_t)(wrow + row) * p.o_row_stride + ch * 8) = val;
-            }
+            if (wrow + row < sq && ch * 8 < p.d) *(u32x4 *)(op + (int64_t)(wrow + row) * p.o_row_stride + ch * 8) = val[i];
         }
     }
 }

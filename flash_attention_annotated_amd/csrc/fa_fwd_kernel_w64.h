@@ -328,6 +328,21 @@ __device__ __forceinline__ void drain_scores(f32x16 &s0, f32x16 &s1) {
 #define FA_ABLATE 0
 #endif
 
+// Developer-only phase timestamps (never shipped: -DFA_TIMING builds, tools/wg_phases.py): every wave drops the 100 MHz
+// wall clock into 64 spare LDS bytes (per wave) behind the K/V rings (LDS traffic only: the loop's manual vmcnt accounting is not
+// disturbed) and copies them to fa_timing_buf[workgroup][wave][8] at the very end.
+#ifdef FA_TIMING
+__device__ unsigned long long fa_timing_buf[32 * 4096];
+// (every lane stores -- same address, same value per wave: a lane-0 branch would be jump-threaded across the phases by
+//  hipcc and drag the wave-uniform LDS-DMA bases into VGPRs)
+#ifndef FA_TMASK
+#define FA_TMASK 255
+#endif
+#define FA_T(i) do { if constexpr ((FA_TMASK >> (i)) & 1) ((unsigned long long *)(smem + 6 * BLOCK_N * D * 2))[(threadIdx.x >> 6) * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define FA_T(i)
+#endif
+
 template <typename T, int D, bool SOFTCAP>
 __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     constexpr int NT = 256;
@@ -382,6 +397,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     }
     const int row_lo = m_block * BLOCK_M;
     if (row_lo >= sq) return;
+    FA_T(0);
 
     o_base += split * p.o_split_stride;  // split-KV: partial results of split s (0 when off)
     lse_base += split * p.lse_split_stride;
@@ -405,6 +421,11 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     // (scale * descale is a VALU product: bring it back to an SGPR by value, not by int conversion)
     float csc_arg = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sc.scale_log2)));
     asm volatile("" : "+s"(k_rs64), "+s"(v_rs64), "+s"(csc_arg));
+    // the two factors of the epilogue, as scalars as well: in VGPRs they are spilled to scratch across the main loop and
+    // each reload is an awaited memory round trip in the epilogue (~1 us apiece); an SGPR spills to a VGPR lane
+    float scale_e = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sc.scale)));
+    float vdesc_e = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sc.v_descale)));
+    asm volatile("" : "+s"(scale_e), "+s"(vdesc_e));
 
     const int shift = sk - sq;
     const int row_hi = min(sq, row_lo + BLOCK_M);
@@ -429,22 +450,23 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     jend = __builtin_amdgcn_readfirstlane(jend);
 
     // ---- Q fragments (B operand of S^T = K.Q^T) -------------------------------------------------------
+    // Branch-free: rows past the end are clamped to the last one and head-dim chunks past d to chunk 0, then zeroed by
+    // selects.  The loads are a lane-per-row gather (32 B of each 128-B line per instruction): ~4 us until they are
+    // back at D = 128 (tools/wg_phases.py), the largest single piece of the per-workgroup fixed cost.
     u32x4 qa[KSTEPS], qb[KSTEPS];
+    {
+        const T *qra = qp + (int64_t)min(row_a, sq - 1) * p.q_row_stride;
+        const T *qrb = qp + (int64_t)min(row_b, sq - 1) * p.q_row_stride;
 #pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) {
-        const int d0 = ks * 16 + hh * 8;
-        u32x4 va = {0, 0, 0, 0}, vb = {0, 0, 0, 0};
-        if (row_a < sq && d0 < p.d) va = *(const u32x4 *)(qp + (int64_t)row_a * p.q_row_stride + d0);
-        if (row_b < sq && d0 < p.d) vb = *(const u32x4 *)(qp + (int64_t)row_b * p.q_row_stride + d0);
-        qa[ks] = va;
-        qb[ks] = vb;
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const int d0 = ks * 16 + hh * 8;
+            const int dc = d0 < p.d ? d0 : 0;
+            qa[ks] = *(const u32x4 *)(qra + dc);
+            qb[ks] = *(const u32x4 *)(qrb + dc);
+        }
     }
-    // Q is only ever an MFMA operand: pin it into the AGPR half of the register file (born there, stays there)
-#pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) {
-        asm volatile("; pin Q" : "+a"(qa[ks]));
-        asm volatile("; pin Q" : "+a"(qb[ks]));
-    }
+    // (the zeroing selects and the AGPR pin wait for the loads: they sit behind the issue of the first K/V tiles below,
+    //  so that the two HBM round trips overlap)
 
     f32x16 oa[DBLOCKS], ob[DBLOCKS];
     {
@@ -569,9 +591,12 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
                 sb[i] = fast_tanh(sb[i] * sc.softcap_pre);
             }
         }
+        // (both branches rebuild their lane constants from the lane id: kept live across the main loop they are spilled
+        //  to scratch, and the reload is a memory round trip in front of every masked half-step)
         if (p.alibi) {  // wave-uniform; bias on the (soft-capped) score, before masking: src/mask.h:156-186
-            const int k0 = n_min * BLOCK_N + 32 * j + 4 * hh;
-            const int rel_a = row_a + shift - k0, rel_b = row_b + shift - k0;
+            const int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            const int k0 = n_min * BLOCK_N + 32 * j + 4 * (ln >> 5);
+            const int rel_a = wrow + (ln & 31) + shift - k0, rel_b = rel_a + 32;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int key = (i & 3) + 8 * (i >> 2);
@@ -580,15 +605,17 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
             }
         }
         if (half_needs_mask(j)) {
-            const int k0 = n_min * BLOCK_N + 32 * j + 4 * hh;
+            const int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            const int k0 = n_min * BLOCK_N + 32 * j + 4 * (ln >> 5);
+            const int ra = wrow + (ln & 31) + shift, rb = ra + 32;  // diagonal key of this lane's rows
             int hi_a = sk, hi_b = sk, lo_a = 0, lo_b = 0;  // [lo, hi) visible
             if (p.window_right >= 0) {
-                hi_a = min(sk, row_a + shift + p.window_right + 1);
-                hi_b = min(sk, row_b + shift + p.window_right + 1);
+                hi_a = min(sk, ra + p.window_right + 1);
+                hi_b = min(sk, rb + p.window_right + 1);
             }
             if (p.window_left >= 0) {
-                lo_a = max(0, row_a + shift - p.window_left);
-                lo_b = max(0, row_b + shift - p.window_left);
+                lo_a = max(0, ra - p.window_left);
+                lo_b = max(0, rb - p.window_left);
             }
             hi_a -= k0; hi_b -= k0; lo_a -= k0; lo_b -= k0;
 #pragma unroll
@@ -659,8 +686,25 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
         if (n_min + 2 <= n_max) load_k(n_min + 2, 2);
         if (n_min + 1 < n_max) load_v(n_min + 1, 1);
     }
+    FA_T(1);
+    {
+        const u32x4 z4 = {0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const bool in_d = ks * 16 + hh * 8 < p.d;
+            qa[ks] = (in_d && row_a < sq) ? qa[ks] : z4;
+            qb[ks] = (in_d && row_b < sq) ? qb[ks] : z4;
+        }
+    }
+    // Q is only ever an MFMA operand: pin it into the AGPR half of the register file (born there, stays there)
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+        asm volatile("; pin Q" : "+a"(qa[ks]));
+        asm volatile("; pin Q" : "+a"(qb[ks]));
+    }
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): Q has landed; nothing compiler-visible stays pending
     tile_barrier<0>();                   // first tiles landed (asm LDS-DMA) and visible to every wave
+    FA_T(2);
     int in_flight = 0;                   // LDS-DMA pieces this wave issued at the top of the current tile
 
     // Pipeline state at the boundary in front of half-step j (canonical naming):
@@ -683,6 +727,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
         m_b = half_swap_max(fmaxf(xa, xb));
     }
     __syncthreads();  // every wave has read K tile n_min before tile n_min's end overwrites its buffer
+    FA_T(3);
 
     const int J = 2 * (n_max - n_min);
     // ---- generic half-step: any boundary case (masks, last half-steps of the wave, rescales, redo after the fast
@@ -979,16 +1024,23 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     }
 
     // ---- epilogue ---------------------------------------------------------------------------------------
+    FA_T(4);
     tile_barrier<0>();  // every wave's LDS-DMA (incl. look-ahead tiles past the end) has landed: the ring can be reused
+    FA_T(5);
     drain_all();        // asm MFMA results -> VALU readers
+    // lane constants are rebuilt from the lane id here: the ones computed in front of the main loop were spilled to
+    // scratch by then, and every reload is a separately awaited memory round trip (tools/wg_phases.py: 3.3 us epilogue)
+    const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int r_e = lane_e & 31, hh_e = lane_e >> 5;
+    const int row_a_e = wrow + r_e, row_b_e = wrow + 32 + r_e;
     const float lt_a = half_swap_sum(l_a), lt_b = half_swap_sum(l_b);
     const bool e_a = (lt_a == 0.f) || (lt_a != lt_a), e_b = (lt_b == 0.f) || (lt_b != lt_b);
-    const float inv_a = (e_a ? 1.f : 1.f / lt_a) * sc.v_descale, inv_b = (e_b ? 1.f : 1.f / lt_b) * sc.v_descale;
+    const float inv_a = (e_a ? 1.f : 1.f / lt_a) * vdesc_e, inv_b = (e_b ? 1.f : 1.f / lt_b) * vdesc_e;
     const bool wave_active = wrow < sq;
     if (wave_active) {
-        if (hh == 0) {
-            if (row_a < sq) p.lse[lse_base + row_a] = e_a ? INFINITY : m_a * sc.scale + __logf(lt_a);
-            if (row_b < sq) p.lse[lse_base + row_b] = e_b ? INFINITY : m_b * sc.scale + __logf(lt_b);
+        if (hh_e == 0) {
+            if (row_a_e < sq) p.lse[lse_base + row_a_e] = e_a ? INFINITY : m_a * scale_e + __logf(lt_a);
+            if (row_b_e < sq) p.lse[lse_base + row_b_e] = e_b ? INFINITY : m_b * scale_e + __logf(lt_b);
         }
         char *obuf = smem + wave * (64 * O_ROW_BYTES);
 #pragma unroll
@@ -1000,31 +1052,49 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
                 wa[1] = Elem<T>::pack2(oa[db][4 * g4 + 2] * inv_a, oa[db][4 * g4 + 3] * inv_a);
                 wb[0] = Elem<T>::pack2(ob[db][4 * g4] * inv_b, ob[db][4 * g4 + 1] * inv_b);
                 wb[1] = Elem<T>::pack2(ob[db][4 * g4 + 2] * inv_b, ob[db][4 * g4 + 3] * inv_b);
-                const int col = (db * 32 + 8 * g4 + 4 * hh) * 2;
-                *(u32x2 *)(obuf + r * O_ROW_BYTES + col) = wa;
-                *(u32x2 *)(obuf + (32 + r) * O_ROW_BYTES + col) = wb;
+                const int col = (db * 32 + 8 * g4 + 4 * hh_e) * 2;
+                *(u32x2 *)(obuf + r_e * O_ROW_BYTES + col) = wa;
+                *(u32x2 *)(obuf + (32 + r_e) * O_ROW_BYTES + col) = wb;
             }
     }
     __syncthreads();
     if (wave_active) {
         const char *obuf = smem + wave * (64 * O_ROW_BYTES);
+        // (LDS reads outside the predicate: all of them are issued before the first store; inside it each read is
+        //  waited for in its own exec-masked block -- 16 serial LDS round trips at D = 128)
+        constexpr int NCH = (64 * CH_PER_ROW) / 64;
+        u32x4 val[NCH];
 #pragma unroll
-        for (int i = 0; i < (64 * CH_PER_ROW) / 64; ++i) {
-            const int c = lane + i * 64;
+        for (int i = 0; i < NCH; ++i) {
+            const int c = lane_e + i * 64;
+            val[i] = *(const u32x4 *)(obuf + (c / CH_PER_ROW) * O_ROW_BYTES + (c % CH_PER_ROW) * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = lane_e + i * 64;
             const int row = c / CH_PER_ROW, ch = c % CH_PER_ROW;
-            if (wrow + row < sq && ch * 8 < p.d) {
-                const u32x4 val = *(const u32x4 *)(obuf + row * O_ROW_BYTES + ch * 16);
-                *(u32x4 *)(op + (int64_t)(wrow + row) * p.o_row_stride + ch * 8) = val;
-            }
+            if (wrow + row < sq && ch * 8 < p.d) *(u32x4 *)(op + (int64_t)(wrow + row) * p.o_row_stride + ch * 8) = val[i];
         }
     }
+#ifdef FA_TIMING
+    FA_T(6);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // O stores of this wave retired
+    FA_T(7);
+    if (blockIdx.x < 4096 && (threadIdx.x & 63) < 8)
+        fa_timing_buf[blockIdx.x * 32 + (threadIdx.x >> 6) * 8 + (threadIdx.x & 63)] =
+            ((unsigned long long *)(smem + 6 * BLOCK_N * D * 2))[(threadIdx.x >> 6) * 8 + (threadIdx.x & 63)];
+#endif
 }
 
 template <int D>
 constexpr int smem_bytes_w64() {
     constexpr int kv = 6 * BLOCK_N * D * 2;
     constexpr int o = 4 * 64 * (D * 2 + 16);
+#ifdef FA_TIMING
+    return (kv > o ? kv : o) + 256;
+#else
     return kv > o ? kv : o;
+#endif
 }
 
 }  // namespace fa
