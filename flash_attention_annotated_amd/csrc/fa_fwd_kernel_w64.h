@@ -301,6 +301,12 @@ __device__ __forceinline__ void lds_dma1(uint32_t lds, const void *base, uint32_
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "s"(base), "s"(lds), "v"(off) : "memory");
 }
+// 64 lanes x 4 B (touches one cache line per lane): used to pull lines into the L2 ahead of time, the LDS copy is a dump
+__device__ __forceinline__ void lds_dma_touch(uint32_t lds, const void *base, uint32_t off) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %3, %1\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(base), "s"(lds), "v"(off) : "memory");
+}
 // End of a tile: all but this wave's N youngest LDS-DMA pieces have landed (the N issued at the top of THIS tile
 // may stay in flight: they fill buffers nobody reads before the next-but-one barrier), then the workgroup barrier.
 template <int N>
@@ -338,7 +344,7 @@ __device__ unsigned long long fa_timing_buf[32 * 4096];
 #ifndef FA_TMASK
 #define FA_TMASK 255
 #endif
-#define FA_T(i) do { if constexpr ((FA_TMASK >> (i)) & 1) ((unsigned long long *)(smem + 6 * BLOCK_N * D * 2))[(threadIdx.x >> 6) * 8 + (i)] = wall_clock64(); } while (0)
+#define FA_T(i) do { if constexpr ((FA_TMASK >> (i)) & 1) ((unsigned long long *)(smem + 6 * BLOCK_N * D * 2 + 1024))[(threadIdx.x >> 6) * 8 + (i)] = wall_clock64(); } while (0)
 #else
 #define FA_T(i)
 #endif
@@ -1027,6 +1033,30 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     FA_T(4);
     tile_barrier<0>();  // every wave's LDS-DMA (incl. look-ahead tiles past the end) has landed: the ring can be reused
     FA_T(5);
+    // ---- L2 prefetch for the workgroup that takes this CU next.  Workgroups are dispatched in id order and (apart from
+    // causal imbalance) take equally long, so the successor is id + (number of CUs); it lives on the same XCD (same id mod
+    // 8), i.e. behind the same L2.  Its Q rows are a cold, badly coalesced gather (~4 us: tools/wg_phases.py); touching one
+    // dword of each of their cache lines here, with the whole epilogue (~3 us) in front of the end of this workgroup, turns
+    // that into L2 hits.  The data lands in a 1 KiB dump area of LDS; dense batches only (no cu_seqlens lookups here).
+    if (!p.cu_seqlens_q && !p.seqused_q && p.num_splits <= 1 && p.q_row_stride < (1 << 20)) {
+        const int wg2 = blockIdx.x + 256;
+        const int slot2 = wg2 >> 3;
+        const int tile2 = ((slot2 / p.unit_tiles) * 8 + (wg2 & 7)) * p.unit_tiles + slot2 % p.unit_tiles;  // decode_tile()
+        if (wg2 < p.grid && tile2 < p.num_tiles) {
+            const int per_kvh = p.h_ratio * p.num_m_blocks;
+            const int bk2 = tile2 / per_kvh, r2 = tile2 % per_kvh;
+            const int m_block2 = p.num_m_blocks - 1 - r2 / p.h_ratio;
+            const int head2 = (bk2 % p.h_k) * p.h_ratio + r2 % p.h_ratio;
+            const T *q2 = (const T *)p.q + (int64_t)(bk2 / p.h_k) * p.q_batch_stride + (int64_t)head2 * p.q_head_stride +
+                          (int64_t)(m_block2 * BLOCK_M) * p.q_row_stride;  // wave-uniform
+            const int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            const int row2 = min(wave * 64 + ln, p.seqlen_q - 1 - m_block2 * BLOCK_M);  // row inside the block, clamped
+            const uint32_t off2 = (uint32_t)(row2 * (int)p.q_row_stride) * 2u;
+            const uint32_t dump = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem + 6 * BLOCK_N * D * 2 + wave * 256;
+#pragma unroll
+            for (int line = 0; line < (D * 2) / 128; ++line) lds_dma_touch(dump, q2, off2 + line * 128);
+        }
+    }
     drain_all();        // asm MFMA results -> VALU readers
     // lane constants are rebuilt from the lane id here: the ones computed in front of the main loop were spilled to
     // scratch by then, and every reload is a separately awaited memory round trip (tools/wg_phases.py: 3.3 us epilogue)
@@ -1076,24 +1106,25 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
             if (wrow + row < sq && ch * 8 < p.d) *(u32x4 *)(op + (int64_t)(wrow + row) * p.o_row_stride + ch * 8) = val[i];
         }
     }
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the prefetch's LDS-DMA has landed before this workgroup's LDS is released
 #ifdef FA_TIMING
     FA_T(6);
     __builtin_amdgcn_s_waitcnt(0x0F70);  // O stores of this wave retired
     FA_T(7);
     if (blockIdx.x < 4096 && (threadIdx.x & 63) < 8)
         fa_timing_buf[blockIdx.x * 32 + (threadIdx.x >> 6) * 8 + (threadIdx.x & 63)] =
-            ((unsigned long long *)(smem + 6 * BLOCK_N * D * 2))[(threadIdx.x >> 6) * 8 + (threadIdx.x & 63)];
+            ((unsigned long long *)(smem + 6 * BLOCK_N * D * 2 + 1024))[(threadIdx.x >> 6) * 8 + (threadIdx.x & 63)];
 #endif
 }
 
 template <int D>
 constexpr int smem_bytes_w64() {
-    constexpr int kv = 6 * BLOCK_N * D * 2;
-    constexpr int o = 4 * 64 * (D * 2 + 16);
+    constexpr int kv = 6 * BLOCK_N * D * 2;  // the K/V rings; the O staging of the epilogue (4 x 64 x (2 D + 16)) fits inside
+    static_assert(kv >= 4 * 64 * (D * 2 + 16), "O staging must fit the K/V rings");
 #ifdef FA_TIMING
-    return (kv > o ? kv : o) + 256;
+    return kv + 1024 + 256;  // + dump area of the Q prefetch + time stamps
 #else
-    return kv > o ? kv : o;
+    return kv + 1024;        // + dump area of the Q prefetch (4 waves x 256 B)
 #endif
 }
 
