@@ -362,10 +362,10 @@ int head_dim_tile(int d) {
     return 256;
 }
 
-template <typename T, int D, int NWAVES, bool SOFTCAP>
+template <typename T, int D, int NWAVES, bool SOFTCAP, bool DROPOUT = false>
 int launch(const fa::KParams &kp, hipStream_t stream) {
     constexpr int smem = fa::smem_bytes<D, NWAVES>();
-    auto kernel = fa::fwd_kernel<T, D, NWAVES, SOFTCAP>;
+    auto kernel = fa::fwd_kernel<T, D, NWAVES, SOFTCAP, DROPOUT>;
     // the > 64 KiB dynamic-LDS opt-in is a per-device attribute of the kernel: one bit per device ordinal
     static std::atomic<uint64_t> attr_set{0};
     int dev = 0;
@@ -410,6 +410,10 @@ int dispatch_variant(const fa::KParams &kp, bool softcap, int variant, hipStream
     // variant 1  : 8 waves x 32 rows (BLOCK_M 256), two waves per SIMD (fa_fwd_kernel.h)
     // variant 2  : 4 waves x 32 rows (BLOCK_M 128)
     // D = 256 does not fit the w64 register budget (O alone would be 256 registers): 4 waves x 32 rows.
+    if (kp.drop_thr < 255) {  // dropout: its own instantiation of the compiler-scheduled shape (never with softcap)
+        if constexpr (D == 256) return launch<T, D, 4, false, true>(kp, stream);
+        else return launch<T, D, 8, false, true>(kp, stream);
+    }
     if constexpr (D == 256) {
         if (softcap) return launch<T, D, 4, true>(kp, stream);
         return launch<T, D, 4, false>(kp, stream);
@@ -626,6 +630,7 @@ int fa_fwd_validate(const fa_fwd_params *p) {
     if (!(p->p_dropout >= 0.f && p->p_dropout < 1.f)) return FA_ERR_BAD_SHAPE;  // "p_dropout must be in [0, 1)"
     if (p->p_dropout > 0.f) {
         if (fp8 || p->block_table || p->kv_batch_idx || p->leftpad_k) return FA_ERR_UNSUPPORTED;  // training path only
+        if (p->softcap > 0.f) return FA_ERR_UNSUPPORTED;  // "Softcapping does not support dropout for now" (flash_api.cpp:377)
         if (!p->rng_state || reinterpret_cast<uintptr_t>(p->rng_state) % 8 != 0) return FA_ERR_NULL_POINTER;
     } else if (p->s_dmask) {
         return FA_ERR_UNSUPPORTED;  // the randval tensor only exists under dropout

@@ -141,6 +141,11 @@ template <> struct Elem<__bf16> {
     static __device__ __forceinline__ void mma_agpr(f32x16 &c, u32x4 a, u32x4 b) {
         asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
     }
+    // score step with the Q fragment (B operand) living in an AGPR: c (VGPRs) += a . q.  s_nop 1: c / a may have been
+    // written by VALU / LDS-return just before; the caller drains the pipe before VALU reads c (hipcc pads nothing here)
+    static __device__ __forceinline__ void mma_qa(f32x16 &c, u32x4 a, u32x4 &q) {
+        asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %2, %1, %0" : "+v"(c), "+a"(q) : "v"(a));
+    }
     static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
         bf16x2 v = {(__bf16)lo, (__bf16)hi};  // v_cvt_pk_bf16_f32, round-to-nearest-even
         return __builtin_bit_cast(uint32_t, v);
@@ -152,6 +157,11 @@ template <> struct Elem<_Float16> {
     }
     static __device__ __forceinline__ void mma_agpr(f32x16 &c, u32x4 a, u32x4 b) {
         asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    }
+    // score step with the Q fragment (B operand) living in an AGPR: c (VGPRs) += a . q.  s_nop 1: c / a may have been
+    // written by VALU / LDS-return just before; the caller drains the pipe before VALU reads c (hipcc pads nothing here)
+    static __device__ __forceinline__ void mma_qa(f32x16 &c, u32x4 a, u32x4 &q) {
+        asm("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %2, %1, %0" : "+v"(c), "+a"(q) : "v"(a));
     }
     static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
         f16x2 v = {(_Float16)lo, (_Float16)hi};  // round-to-nearest-even
@@ -221,7 +231,9 @@ __device__ __forceinline__ float max3(float a, float b, float c) {
     return r;
 }
 
-template <typename T, int D, int NWAVES, bool SOFTCAP>
+// DROPOUT is a compile-time switch: as a run-time branch its bookkeeping sat in every instantiation and cost the
+// decode shape (D = 128, 4 waves, 256-register budget) a third of its speed in extra spills.
+template <typename T, int D, int NWAVES, bool SOFTCAP, bool DROPOUT = false>
 __global__ __launch_bounds__(NWAVES * 64, (D <= 128 ? 2 : 1)) void fwd_kernel(const KParams p) {
     constexpr int NT = NWAVES * 64;
     constexpr int BLOCK_M = NWAVES * 32;
@@ -277,11 +289,12 @@ __global__ __launch_bounds__(NWAVES * 64, (D <= 128 ? 2 : 1)) void fwd_kernel(co
     if (row_lo >= sq) return;  // whole workgroup: nothing to do (varlen / padded grid)
     const Scales sc = load_scales(p, batch, kv_head);
     const float alibi = load_alibi(p, sc, batch, head);
-    // dropout bookkeeping (only read when p.drop_thr < 255)
-    const uint32_t seed_mix = p.drop_thr < 255 ? fa_seed_mix(p.rng_state, batch * p.h + head) : 0u;
+    // dropout bookkeeping
+    uint32_t seed_mix = 0u;
+    if constexpr (DROPOUT) seed_mix = fa_seed_mix(p.rng_state, batch * p.h + head);
     int64_t dmask_base = 0;  // s_dmask: dense (b, h, sq, sk), varlen (h, total_q, max_seqlen_k)
     const int64_t dmask_rs = p.seqlen_k;
-    if (p.s_dmask) {
+    if (DROPOUT && p.s_dmask) {
         if (p.cu_seqlens_q) dmask_base = ((int64_t)head * p.total_q + p.cu_seqlens_q[batch]) * p.seqlen_k;
         else dmask_base = ((int64_t)batch * p.h + head) * p.seqlen_q * (int64_t)p.seqlen_k;
     }
@@ -329,6 +342,14 @@ __global__ __launch_bounds__(NWAVES * 64, (D <= 128 ? 2 : 1)) void fwd_kernel(co
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) qf[ks] = (ks * 16 + hh * 8 < p.d && my_row < sq) ? qf[ks] : z4;
     }
+    // D = 256: 16 Q fragments = 64 registers that only MFMAs read.  Pinned into the AGPR half of the register file they
+    // stop competing with the softmax for arch VGPRs (the compiler-placed version spilled ~10 registers to scratch and
+    // reloaded them inside every tile: one wave per SIMD here, nothing hides those round trips).
+    constexpr bool Q_IN_AGPR = (D == 256);
+    if constexpr (Q_IN_AGPR) {
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) asm volatile("; pin Q" : "+a"(qf[ks]));
+    }
 
     // ---- accumulators --------------------------------------------------------------------------
     f32x16 o_acc[DBLOCKS];
@@ -346,14 +367,12 @@ __global__ __launch_bounds__(NWAVES * 64, (D <= 128 ? 2 : 1)) void fwd_kernel(co
     // K chunk meets a zero Q chunk, so finite duplicates contribute exactly 0.  No predication means
     // no exec-masked branches and no conservative vmcnt waits in front of the MFMAs.
     u32x4 kreg[LD_PER_THREAD], vreg[LD_PER_THREAD];
-    int ld_row[LD_PER_THREAD], ld_col[LD_PER_THREAD];
-#pragma unroll
-    for (int i = 0; i < LD_PER_THREAD; ++i) {
-        const int c = tid + i * NT;
-        ld_row[i] = c / CH_PER_ROW;
-        const int ch = c % CH_PER_ROW;
-        ld_col[i] = (ch * 8 < p.d) ? ch * 8 : 0;
-    }
+    // thread t stages chunk (t % CH_PER_ROW) of rows t / CH_PER_ROW + i * ROWS_PER_PASS: two lane constants, the rest are
+    // immediates (as per-i arrays they were 2 LD_PER_THREAD live registers that hipcc spilled and reloaded every tile)
+    static_assert(NT % CH_PER_ROW == 0, "a pass of the workgroup covers whole rows");
+    constexpr int ROWS_PER_PASS = NT / CH_PER_ROW;
+    const int ld_row0 = tid / CH_PER_ROW;
+    const int ld_col0 = ((tid % CH_PER_ROW) * 8 < p.d) ? (tid % CH_PER_ROW) * 8 : 0;
     const int k_rs = (int)p.k_row_stride, v_rs = (int)p.v_row_stride;  // host guarantees 64 * stride < 2^31
     auto load_tile = [&](int n) {
         const int k0 = n * BLOCK_N;
@@ -368,21 +387,21 @@ __global__ __launch_bounds__(NWAVES * 64, (D <= 128 ? 2 : 1)) void fwd_kernel(co
             } else {  // any other page size (FA3: "page_block_size can be arbitrary"): the page is looked up per row
 #pragma unroll
                 for (int i = 0; i < LD_PER_THREAD; ++i) {
-                    const int row = k0 + min(ld_row[i], last);
+                    const int row = k0 + min(ld_row0 + i * ROWS_PER_PASS, last);
                     const int pi = row / p.page_size;
                     const int64_t page = pages[pi];
                     const int in_page = row - pi * p.page_size;
-                    kreg[i] = *(const u32x4 *)(kp + page * p.k_batch_stride + (int64_t)in_page * p.k_row_stride + ld_col[i]);
-                    vreg[i] = *(const u32x4 *)(vp + page * p.v_batch_stride + (int64_t)in_page * p.v_row_stride + ld_col[i]);
+                    kreg[i] = *(const u32x4 *)(kp + page * p.k_batch_stride + (int64_t)in_page * p.k_row_stride + ld_col0);
+                    vreg[i] = *(const u32x4 *)(vp + page * p.v_batch_stride + (int64_t)in_page * p.v_row_stride + ld_col0);
                 }
                 return;
             }
         }
 #pragma unroll
         for (int i = 0; i < LD_PER_THREAD; ++i) {
-            const int row = min(ld_row[i], last);
-            kreg[i] = *(const u32x4 *)(kt + (uint32_t)(row * k_rs + ld_col[i]));
-            vreg[i] = *(const u32x4 *)(vt + (uint32_t)(row * v_rs + ld_col[i]));
+            const int row = min(ld_row0 + i * ROWS_PER_PASS, last);
+            kreg[i] = *(const u32x4 *)(kt + (uint32_t)(row * k_rs + ld_col0));
+            vreg[i] = *(const u32x4 *)(vt + (uint32_t)(row * v_rs + ld_col0));
         }
     };
     auto store_tile = [&](int buf) {
@@ -444,9 +463,15 @@ __global__ __launch_bounds__(NWAVES * 64, (D <= 128 ? 2 : 1)) void fwd_kernel(co
                 const int off = kbase ^ (32 * ks);  // = lds_off<D>(r, 2 ks + hh): the swizzle XORs chunk bits 0-3 only
                 const u32x4 kf0 = *(const u32x4 *)(kbuf + off);
                 const u32x4 kf1 = *(const u32x4 *)(kbuf + off + 32 * D * 2);
-                s[0] = Elem<T>::mma(kf0, qf[ks], s[0]);
-                s[1] = Elem<T>::mma(kf1, qf[ks], s[1]);
+                if constexpr (Q_IN_AGPR) {
+                    Elem<T>::mma_qa(s[0], kf0, qf[ks]);
+                    Elem<T>::mma_qa(s[1], kf1, qf[ks]);
+                } else {
+                    s[0] = Elem<T>::mma(kf0, qf[ks], s[0]);
+                    s[1] = Elem<T>::mma(kf1, qf[ks], s[1]);
+                }
             }
+            if constexpr (Q_IN_AGPR) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(s[0]), "+v"(s[1]));  // asm MFMA results -> VALU
 
             if constexpr (SOFTCAP) {
 #pragma unroll
@@ -508,7 +533,7 @@ __global__ __launch_bounds__(NWAVES * 64, (D <= 128 ? 2 : 1)) void fwd_kernel(co
                 }
             l_run += psum;  // (the normaliser sums the probabilities BEFORE dropout)
 
-            if (p.drop_thr < 255) {  // wave-uniform: dropout of the probabilities that feed the PV product
+            if constexpr (DROPOUT) {  // dropout of the probabilities that feed the PV product
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
