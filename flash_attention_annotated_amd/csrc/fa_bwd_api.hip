@@ -43,7 +43,7 @@ int64_t unit_grid(int64_t tiles, int blocks) {
     return 8 * ((units + 7) / 8) * blocks;
 }
 
-template <typename T, int D, bool SOFTCAP>
+template <typename T, int D, bool SOFTCAP, bool DROPOUT = false>
 int run_bwd(fa::BParams bp, int rows_q_max, int rows_k_max, hipStream_t stream) {
     // 32-wide blocks per wave (every LDS fragment feeds NB MFMAs): two wherever accumulators + resident operands fit
     // the 512-register budget of a lone wave.  dQ: 2 for D <= 128; dK/dV (two accumulator sets + K and V): 2 for D = 64
@@ -74,7 +74,7 @@ int run_bwd(fa::BParams bp, int rows_q_max, int rows_k_max, hipStream_t stream) 
             const int64_t grid = unit_grid(tiles, bp.num_blocks);
             if (grid > 0x7fffffff) return FA_ERR_BAD_SHAPE;
             bp.grid = (int32_t)grid;
-            const int st = launch_kernel(fa::bwd_dkdv_kernel<T, D, NBK, SOFTCAP>, fa::smem_bytes_dkdv<D>(), attr, bp.grid, 256, bp, stream);
+            const int st = launch_kernel(fa::bwd_dkdv_kernel<T, D, NBK, SOFTCAP, DROPOUT>, fa::smem_bytes_dkdv<D>(), attr, bp.grid, 256, bp, stream);
             if (st != FA_OK) return st;
         }
     }
@@ -89,7 +89,7 @@ int run_bwd(fa::BParams bp, int rows_q_max, int rows_k_max, hipStream_t stream) 
             const int64_t grid = unit_grid(tiles, bp.num_blocks);
             if (grid > 0x7fffffff) return FA_ERR_BAD_SHAPE;
             bp.grid = (int32_t)grid;
-            const int st = launch_kernel(fa::bwd_dq_kernel<T, D, NBQ, SOFTCAP>, fa::smem_bytes_dq<D>(), attr, bp.grid, 256, bp, stream);
+            const int st = launch_kernel(fa::bwd_dq_kernel<T, D, NBQ, SOFTCAP, DROPOUT>, fa::smem_bytes_dq<D>(), attr, bp.grid, 256, bp, stream);
             if (st != FA_OK) return st;
         }
     }
@@ -98,10 +98,17 @@ int run_bwd(fa::BParams bp, int rows_q_max, int rows_k_max, hipStream_t stream) 
 
 template <typename T>
 int dispatch_bwd(const fa::BParams &bp, bool softcap, int sq, int sk, hipStream_t stream) {
+    const bool drop = bp.drop_thr < 255;  // (never together with softcap: fa_bwd_validate)
     switch (head_dim_tile_b(bp.d)) {
-        case 64: return softcap ? run_bwd<T, 64, true>(bp, sq, sk, stream) : run_bwd<T, 64, false>(bp, sq, sk, stream);
-        case 128: return softcap ? run_bwd<T, 128, true>(bp, sq, sk, stream) : run_bwd<T, 128, false>(bp, sq, sk, stream);
-        default: return softcap ? run_bwd<T, 256, true>(bp, sq, sk, stream) : run_bwd<T, 256, false>(bp, sq, sk, stream);
+        case 64:
+            if (drop) return run_bwd<T, 64, false, true>(bp, sq, sk, stream);
+            return softcap ? run_bwd<T, 64, true>(bp, sq, sk, stream) : run_bwd<T, 64, false>(bp, sq, sk, stream);
+        case 128:
+            if (drop) return run_bwd<T, 128, false, true>(bp, sq, sk, stream);
+            return softcap ? run_bwd<T, 128, true>(bp, sq, sk, stream) : run_bwd<T, 128, false>(bp, sq, sk, stream);
+        default:
+            if (drop) return run_bwd<T, 256, false, true>(bp, sq, sk, stream);
+            return softcap ? run_bwd<T, 256, true>(bp, sq, sk, stream) : run_bwd<T, 256, false>(bp, sq, sk, stream);
     }
 }
 
@@ -117,6 +124,7 @@ int fa_bwd_validate(const fa_bwd_params *p) {
     if (p->dtype != FA_DTYPE_FP16 && p->dtype != FA_DTYPE_BF16) return FA_ERR_BAD_DTYPE;
     if (!(p->p_dropout >= 0.f && p->p_dropout < 1.f)) return FA_ERR_BAD_SHAPE;
     if (p->p_dropout > 0.f && (!p->rng_state || reinterpret_cast<uintptr_t>(p->rng_state) % 8 != 0)) return FA_ERR_NULL_POINTER;
+    if (p->p_dropout > 0.f && p->softcap > 0.f) return FA_ERR_UNSUPPORTED;  // "Softcapping does not support dropout for now"
     if (p->b <= 0 || p->h <= 0 || p->h_k <= 0 || p->seqlen_q < 0 || p->seqlen_k < 0) return FA_ERR_BAD_SHAPE;
     if (p->d <= 0 || p->d > 256 || p->d % 8 != 0) return FA_ERR_BAD_HEAD_DIM;
     if (p->h % p->h_k != 0) return FA_ERR_BAD_HEADS;

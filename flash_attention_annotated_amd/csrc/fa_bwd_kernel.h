@@ -216,7 +216,8 @@ __global__ __launch_bounds__(256) void bwd_dot_kernel(const BParams p) {
 
 // Elementwise core shared by both kernels: from raw score x and dP to (P, dS) for one (query i, key j).
 // `visible` is only looked at when MASK (boundary tiles); rows past the end of q carry LSE = +inf, i.e. P = 0.
-template <bool SOFTCAP, bool MASK>
+// (DROPOUT is a compile-time switch: as a run-time branch it cost the plain backward 2.2 %, same-box A/B)
+template <bool SOFTCAP, bool MASK, bool DROPOUT>
 __device__ __forceinline__ void bwd_point(const BParams &p, float x, float dp, float lse2, float dsum, float alibi2,
                                           int rel /* i + sk - sq - j */, bool visible, uint32_t seed_mix, int qi, int key,
                                           float &pv, float &ds) {
@@ -232,7 +233,7 @@ __device__ __forceinline__ void bwd_point(const BParams &p, float x, float dp, f
     if constexpr (MASK) pv = visible ? pv : 0.f;
     bool keep = true;
     if constexpr (MASK) {
-        if (p.drop_thr < 255) {  // O = (keep . P / (1 - p)) V: dP picks up the same factor, D = rowsum(dO . O) still holds
+        if constexpr (DROPOUT) {  // O = (keep . P / (1 - p)) V: dP picks up the same factor, D = rowsum(dO . O) still holds
             keep = fa_rand8(seed_mix, (uint32_t)qi, (uint32_t)key) <= (uint32_t)p.drop_thr;
             dp = keep ? dp * p.rp_dropout : 0.f;
         }
@@ -240,7 +241,7 @@ __device__ __forceinline__ void bwd_point(const BParams &p, float x, float dp, f
     ds = pv * (dp - dsum);
     if constexpr (SOFTCAP) ds *= (1.f - t * t);
     if constexpr (MASK) {
-        if (p.drop_thr < 255) pv = keep ? pv * p.rp_dropout : 0.f;  // the P that multiplies dO in dV
+        if constexpr (DROPOUT) pv = keep ? pv * p.rp_dropout : 0.f;  // the P that multiplies dO in dV
     }
 }
 
@@ -248,7 +249,7 @@ __device__ __forceinline__ void bwd_point(const BParams &p, float x, float dp, f
 // dK / dV.  NB = 32-key blocks per wave: every Q / dO / Q^T / dO^T fragment read from LDS feeds NB MFMAs (the
 // one-block form moves 1 KiB of LDS per MFMA, which is the LDS bandwidth limit of the CU).
 // ------------------------------------------------------------------------------------------------------------------
-template <typename T, int D, int NB, bool SOFTCAP>
+template <typename T, int D, int NB, bool SOFTCAP, bool DROPOUT = false>
 __global__ __launch_bounds__(256, 1) void bwd_dkdv_kernel(const BParams p) {
     constexpr int NT = 256;
     constexpr int WKEYS = 32 * NB;             // keys per wave
@@ -325,7 +326,9 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_kernel(const BParams p) {
     // no AGPR temporaries left and rotates the whole file around the asm statements; there only dV is pinned and dK
     // stays compiler-managed (measured: 5.8 -> 5.0 ms on b2 s4096 h8 d256).
     constexpr bool PIN_ACC = 2 * NB * DBLOCKS * 16 < 256;  // dK (and dV)
-    constexpr bool PIN_DV = true;
+    // (D = 256 with dropout: the extra live state makes hipcc move the pinned tiles around inside MFMA hazard windows;
+    //  that rare combination runs on compiler-managed accumulators)
+    constexpr bool PIN_DV = !(D == 256 && DROPOUT);
     f32x16 dk_acc[NB * DBLOCKS], dv_acc[NB * DBLOCKS];  // [nb * DBLOCKS + db]
     {
         const u32x4 z4 = {0, 0, 0, 0};
@@ -337,7 +340,14 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_kernel(const BParams p) {
                 for (int e = 0; e < 16; ++e) dk_acc[i][e] = 0.f;
             }
             if constexpr (PIN_DV) Mfma<T>::o_zero(dv_acc[i], z4);
+            else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) dv_acc[i][e] = 0.f;
+            }
         }
+        // (hipcc may spill an accumulator to scratch right here -- it does at D = 256: let the matrix pipe finish first)
+        if constexpr (PIN_ACC) drain_acc(dk_acc);
+        if constexpr (PIN_DV) drain_acc(dv_acc);
     }
 
     // ---- Q / dO tile staging: rows clamped into the sequence (clamped rows are masked).  LDS-DMA
@@ -436,7 +446,7 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_kernel(const BParams p) {
 
         const int head = tile_head(it), row0 = tile_row0(it);
         const float alibi2 = p.alibi ? p.alibi[(int64_t)batch * p.alibi_bs + head] * LOG2E : 0.f;
-        const uint32_t seed_mix = p.drop_thr < 255 ? fa_seed_mix(p.rng_state, batch * p.h + head) : 0u;
+        const uint32_t seed_mix = DROPOUT ? fa_seed_mix(p.rng_state, batch * p.h + head) : 0u;
         const char *qbuf = smem + cur * TILE_BYTES;
         const char *gbuf = smem + (2 + cur) * TILE_BYTES;
 
@@ -449,7 +459,7 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_kernel(const BParams p) {
         bool need_mask = (key_w0 + WKEYS > sk) || (row0 + BM > sq);
         if (p.window_right >= 0) need_mask = need_mask || (key_w0 + WKEYS - 1 > row0 + shift + p.window_right);
         if (p.window_left >= 0) need_mask = need_mask || (key_w0 < row0 + BM - 1 + shift - p.window_left);
-        need_mask = need_mask || (p.drop_thr < 255);
+        need_mask = need_mask || DROPOUT;
 
         if (!skip) {
 #pragma unroll
@@ -504,7 +514,7 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_kernel(const BParams p) {
                                     if (p.window_left >= 0) vis = vis && (rel <= p.window_left);
                                 }
                                 float pv, ds;
-                                bwd_point<SOFTCAP, MASK>(p, s[nb][i], dp[nb][i], lv[e], dsv[e], alibi2, rel, vis, seed_mix, qi, my_key, pv, ds);
+                                bwd_point<SOFTCAP, MASK, DROPOUT>(p, s[nb][i], dp[nb][i], lv[e], dsv[e], alibi2, rel, vis, seed_mix, qi, my_key, pv, ds);
                                 s[nb][i] = pv;
                                 dp[nb][i] = ds;
                             }
@@ -554,7 +564,8 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_kernel(const BParams p) {
                     const int db = t >> 1, st = t & 1;
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) {  // (s_nop 1 in front: VALU-packed P / dS -> MFMA operand)
-                        Mfma<T>::o_acc_pad(dv_acc[nb * DBLOCKS + db], gt, pf[nb][st]);
+                        if constexpr (PIN_DV) Mfma<T>::o_acc_pad(dv_acc[nb * DBLOCKS + db], gt, pf[nb][st]);
+                        else dv_acc[nb * DBLOCKS + db] = Elem<T>::mma(gt, pf[nb][st], dv_acc[nb * DBLOCKS + db]);
                         if constexpr (PIN_ACC) Mfma<T>::o_acc_pad(dk_acc[nb * DBLOCKS + db], qt, dsf[nb][st]);
                         else dk_acc[nb * DBLOCKS + db] = Elem<T>::mma(qt, dsf[nb][st], dk_acc[nb * DBLOCKS + db]);
                     }
@@ -616,7 +627,7 @@ constexpr int smem_bytes_dkdv() {
 // ------------------------------------------------------------------------------------------------------------------
 // dQ.  NB = 32-row query blocks per wave (K / V / K^T fragments from LDS feed NB MFMAs each).
 // ------------------------------------------------------------------------------------------------------------------
-template <typename T, int D, int NB, bool SOFTCAP>
+template <typename T, int D, int NB, bool SOFTCAP, bool DROPOUT = false>
 __global__ __launch_bounds__(256, 1) void bwd_dq_kernel(const BParams p) {
     constexpr int NT = 256;
     constexpr int WROWS = 32 * NB;
@@ -694,7 +705,7 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_kernel(const BParams p) {
         }
     }
     const float alibi2 = p.alibi ? p.alibi[(int64_t)batch * p.alibi_bs + head] * LOG2E : 0.f;
-    const uint32_t seed_mix = p.drop_thr < 255 ? fa_seed_mix(p.rng_state, batch * p.h + head) : 0u;
+    const uint32_t seed_mix = DROPOUT ? fa_seed_mix(p.rng_state, batch * p.h + head) : 0u;
 
     f32x16 dq_acc[NB * DBLOCKS];  // [nb * DBLOCKS + db], AGPRs
     {
@@ -787,7 +798,7 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_kernel(const BParams p) {
         bool need_mask = (k0 + BLOCK_N > sk);
         if (p.window_right >= 0) need_mask = need_mask || (k0 + BLOCK_N - 1 > wrow + shift + p.window_right);
         if (p.window_left >= 0) need_mask = need_mask || (k0 < wrow + WROWS - 1 + shift - p.window_left);
-        need_mask = need_mask || (p.drop_thr < 255);
+        need_mask = need_mask || DROPOUT;
 
         if (!skip) {
             const char *kbuf = smem + cur * TILE_BYTES;
@@ -835,7 +846,7 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_kernel(const BParams p) {
                                 if (p.window_left >= 0) vis = vis && (rel <= p.window_left);
                             }
                             float pv, ds;
-                            bwd_point<SOFTCAP, MASK>(p, s[nb][i], dp[nb][i], lse2[nb], dsum[nb], alibi2, rel, vis, seed_mix, my_row, key, pv, ds);
+                            bwd_point<SOFTCAP, MASK, DROPOUT>(p, s[nb][i], dp[nb][i], lse2[nb], dsum[nb], alibi2, rel, vis, seed_mix, my_row, key, pv, ds);
                             dp[nb][i] = ds;
                         }
                     }
