@@ -23,3 +23,25 @@ def test_no_unpadded_mfma_or_trans_hazards(tmp_path, unit):
                    check=True, stderr=subprocess.DEVNULL)
     violations = isa_hazards.scan(str(out))
     assert not violations, violations[:5]
+    # (c) register spills: a scratch reload is an awaited memory round trip.  The pipelined forward kernel has none at all;
+    #     the compiler-scheduled forward shapes have none between the first and the last MFMA of their tile loop (soft-cap
+    #     instantiations may keep one between the two products); the backward kernels none for head dims <= 128.
+    import re
+    txt = open(out).read()
+    for m in re.finditer(r"^(_ZN2fa\w+):.*?\n(.*?)\.end_amdhsa_kernel", txt, re.S | re.M):
+        name, lines = m.group(1), m.group(2).split("\n")
+        total = sum("v_mfma" in l for l in lines)
+        n, inside, any_scratch = 0, [], 0
+        for l in lines:
+            n += "v_mfma" in l
+            if "scratch_" in l:
+                any_scratch += 1
+                if "scratch_load" in l and 0 < n < total:
+                    inside.append(n)
+        if "fwd_kernel_w64" in name:
+            assert any_scratch == 0, (name, any_scratch)
+        elif "fwd_kernel" in name:
+            softcap = re.search(r"Li\d+ELi\d+ELb1", name) is not None
+            assert len(inside) <= (1 if softcap else 0), (name, inside)
+        elif "bwd_" in name and "Li256E" not in name:
+            assert any_scratch == 0, (name, any_scratch)

@@ -16,6 +16,10 @@ timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLIC
 timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/pmc_c -o c2 -- python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline > /dev/null 2> $R/pmc_c.err
 timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $R/pmc_d -o c2 -- python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline > /dev/null 2> $R/pmc_d.err
 python tools/pmc_sum.py $R/pmc_a $R/pmc_b $R/pmc_c $R/pmc_d > $R/pmc_summary.txt
+timeout -k 10 300 python tools/fwd_grid.py 0 2>&1 | grep -v amdgpu > $R/fwd_grid.txt
+timeout -k 10 200 python tools/d256_bench.py 2>&1 | grep -v amdgpu > $R/d256.txt
+timeout -k 10 200 python tools/decode_sweep.py 2>&1 | grep -v amdgpu > $R/decode_sweep.txt
+timeout -k 10 200 python tools/dropout_bench.py 2>&1 | grep -v amdgpu > $R/dropout.txt
 python - <<'PY'
 import json
 for w in ("c2", "c3", "c4", "c5", "c2_bwd", "c3_bwd", "decode"):
