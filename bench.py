@@ -139,8 +139,10 @@ def cpu_baseline(w, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    # defaults: long enough for the clocks to settle (30 steps after 5 warm-ups read ~2 % low: the first launches of a
+    # process run at a lower clock), still well under a second of GPU time for every workload
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))  # c2 = BASELINE metric config
     ap.add_argument("--variant", type=int, default=0, help="kernel variant override (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

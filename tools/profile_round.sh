@@ -8,7 +8,7 @@ tail -1 $R/pytest_gpu.log
 timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids
 timeout -k 10 300 python bench.py > $R/bench_c2.json 2> $R/bench_c2.err
 for w in c3 c4 c5 c2_bwd c3_bwd decode; do timeout -k 10 200 python bench.py --workload $w --no-cpu-baseline > $R/bench_$w.json 2> $R/bench_$w.err; done
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/kt -o c2 -- python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline > $R/kt_bench.json 2> $R/kt.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/kt -o c2 -- python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline > $R/kt_bench.json 2> $R/kt.err
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/kt_bwd -o c2b -- python3 bench.py --workload c2_bwd --steps 10 --warmup 2 --no-cpu-baseline > $R/kt_bwd_bench.json 2> $R/kt_bwd.err
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/kt_dec -o dec -- python3 bench.py --workload decode --steps 20 --warmup 3 > $R/kt_dec_bench.json 2> $R/kt_dec.err
 timeout -k 10 200 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --output-format csv -d $R/pmc_a -o c2 -- python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline > /dev/null 2> $R/pmc_a.err
