@@ -3,7 +3,7 @@ run() { if [ -n "$1" ]; then FA_FWD_LIB=$1 "${@:2}"; else "${@:2}"; fi; }
 for i in 1 2; do
   for lib in "$1" ""; do
     for w in c2 c3; do
-      run "$lib" python bench.py --workload $w --no-cpu-baseline --steps 30 --warmup 5 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$w', 'old' if '$lib' else 'new', d['value'], d['roofline']['kernel_ms_min'])"
+      run "$lib" python bench.py --workload $w --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$w', 'old' if '$lib' else 'new', d['value'], d['roofline']['kernel_ms_min'])"
     done
   done
 done
