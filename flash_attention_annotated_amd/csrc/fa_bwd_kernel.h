@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void bwd_dot_kernel(const BParams p) {
 // (DROPOUT is a compile-time switch: as a run-time branch it cost the plain backward 2.2 %, same-box A/B)
 template <bool SOFTCAP, bool MASK, bool DROPOUT>
 __device__ __forceinline__ void bwd_point(const BParams &p, float x, float dp, float lse2, float dsum, float alibi2,
-                                          int rel /* i + sk - sq - j */, bool visible, uint32_t seed_mix, int qi, int key,
+                                          int rel /* i + sk - sq - j */, bool visible, uint32_t rv /* dropout byte of (i, j) */,
                                           float &pv, float &ds) {
     float t = 0.f, sl;
     if constexpr (SOFTCAP) {
@@ -234,7 +234,7 @@ __device__ __forceinline__ void bwd_point(const BParams &p, float x, float dp, f
     bool keep = true;
     if constexpr (MASK) {
         if constexpr (DROPOUT) {  // O = (keep . P / (1 - p)) V: dP picks up the same factor, D = rowsum(dO . O) still holds
-            keep = fa_rand8(seed_mix, (uint32_t)qi, (uint32_t)key) <= (uint32_t)p.drop_thr;
+            keep = rv <= (uint32_t)p.drop_thr;
             dp = keep ? dp * p.rp_dropout : 0.f;
         }
     }
@@ -502,6 +502,7 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_kernel(const BParams p) {
 #pragma unroll
                         for (int nb = 0; nb < NB; ++nb) {
                             const int my_key = key_w0 + 32 * nb + r;
+                            uint32_t rblk = 0;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 const int i = 4 * g4 + e;
@@ -513,8 +514,13 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_kernel(const BParams p) {
                                     if (p.window_right >= 0) vis = vis && (rel + p.window_right >= 0);
                                     if (p.window_left >= 0) vis = vis && (rel <= p.window_left);
                                 }
+                                uint32_t rv = 0;
+                                if constexpr (DROPOUT) {  // rows qi (e even) and qi + 1 share one hash: byte 2 (e & 1) + (key & 1)
+                                    if ((e & 1) == 0) rblk = fa_rand_block(seed_mix, (uint32_t)qi >> 1, (uint32_t)my_key >> 1) >> (8 * (my_key & 1));
+                                    rv = (rblk >> (16 * (e & 1))) & 255u;
+                                }
                                 float pv, ds;
-                                bwd_point<SOFTCAP, MASK, DROPOUT>(p, s[nb][i], dp[nb][i], lv[e], dsv[e], alibi2, rel, vis, seed_mix, qi, my_key, pv, ds);
+                                bwd_point<SOFTCAP, MASK, DROPOUT>(p, s[nb][i], dp[nb][i], lv[e], dsv[e], alibi2, rel, vis, rv, pv, ds);
                                 s[nb][i] = pv;
                                 dp[nb][i] = ds;
                             }
@@ -835,6 +841,7 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_kernel(const BParams p) {
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) {
                         const int my_row = wrow + 32 * nb + r;
+                        uint32_t rblk = 0;
 #pragma unroll
                         for (int i = 0; i < 16; ++i) {
                             const int key = k0 + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
@@ -845,8 +852,13 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_kernel(const BParams p) {
                                 if (p.window_right >= 0) vis = vis && (rel + p.window_right >= 0);
                                 if (p.window_left >= 0) vis = vis && (rel <= p.window_left);
                             }
+                            uint32_t rv = 0;
+                            if constexpr (DROPOUT) {  // keys key (i even) and key + 1 share one hash
+                                if ((i & 1) == 0) rblk = fa_rand_block(seed_mix, (uint32_t)my_row >> 1, (uint32_t)key >> 1) >> (16 * (my_row & 1));
+                                rv = (rblk >> (8 * (i & 1))) & 255u;
+                            }
                             float pv, ds;
-                            bwd_point<SOFTCAP, MASK, DROPOUT>(p, s[nb][i], dp[nb][i], lse2[nb], dsum[nb], alibi2, rel, vis, seed_mix, my_row, key, pv, ds);
+                            bwd_point<SOFTCAP, MASK, DROPOUT>(p, s[nb][i], dp[nb][i], lse2[nb], dsum[nb], alibi2, rel, vis, rv, pv, ds);
                             dp[nb][i] = ds;
                         }
                     }

@@ -79,15 +79,20 @@ struct KParams {
     float rp_dropout;
 };
 
-// 8-bit counter-based random value of element (batch*h + head, query row, key) for the dropout decision: the three
-// coordinates and the (seed, offset) pair are mixed and pushed through a 32-bit avalanche (lowbias32).  Forward and
-// backward regenerate the same values.
-__device__ __forceinline__ uint32_t fa_rand8(uint32_t seed_mix, uint32_t row, uint32_t key) {
-    uint32_t x = seed_mix ^ (row * 0x9E3779B1u) ^ (key * 0x85EBCA77u + 0x165667B1u);
+// Counter-based random bytes for the dropout decision: ONE 32-bit avalanche (lowbias32) per 2 x 2 block of the score
+// matrix -- rows 2a, 2a+1 x keys 2b, 2b+1 of (batch*h + head) -- gives the four 8-bit values of the block (byte index
+// 2 (row & 1) + (key & 1)).  Every kernel owns pairs of neighbouring elements (two keys of a row in the forward and dQ,
+// two rows of a key in dK/dV), so the hash is evaluated once per two elements.  Forward and backward regenerate the
+// same values.
+__device__ __forceinline__ uint32_t fa_rand_block(uint32_t seed_mix, uint32_t row2, uint32_t key2) {
+    uint32_t x = seed_mix ^ (row2 * 0x9E3779B1u) ^ (key2 * 0x85EBCA77u + 0x165667B1u);
     x ^= x >> 16; x *= 0x7FEB352Du;
     x ^= x >> 15; x *= 0x846CA68Bu;
     x ^= x >> 16;
-    return x >> 24;
+    return x;
+}
+__device__ __forceinline__ uint32_t fa_rand8(uint32_t seed_mix, uint32_t row, uint32_t key) {
+    return (fa_rand_block(seed_mix, row >> 1, key >> 1) >> (8 * (((row & 1) << 1) | (key & 1)))) & 255u;
 }
 __device__ __forceinline__ uint32_t fa_seed_mix(const uint64_t *rng_state, int bh) {
     const uint64_t seed = rng_state[0], off = rng_state[1];
@@ -537,11 +542,17 @@ __global__ __launch_bounds__(NWAVES * 64, (D <= 128 ? 2 : 1)) void fwd_kernel(co
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
+                    for (int i = 0; i < 16; i += 2) {  // elements i, i+1 = keys key, key+1 (key even): one hash
                         const int key = k0 + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-                        const uint32_t rv = fa_rand8(seed_mix, (uint32_t)my_row, (uint32_t)key);
-                        if (rv > (uint32_t)p.drop_thr) s[kb][i] = 0.f;
-                        if (p.s_dmask && my_row < sq && key < sk) p.s_dmask[dmask_base + (int64_t)my_row * dmask_rs + key] = (uint8_t)rv;
+                        const uint32_t x = fa_rand_block(seed_mix, (uint32_t)my_row >> 1, (uint32_t)key >> 1) >> (16 * (my_row & 1));
+                        const uint32_t rv0 = x & 255u, rv1 = (x >> 8) & 255u;
+                        if (rv0 > (uint32_t)p.drop_thr) s[kb][i] = 0.f;
+                        if (rv1 > (uint32_t)p.drop_thr) s[kb][i + 1] = 0.f;
+                        if (p.s_dmask && my_row < sq) {
+                            uint8_t *dm = p.s_dmask + dmask_base + (int64_t)my_row * dmask_rs + key;
+                            if (key < sk) dm[0] = (uint8_t)rv0;
+                            if (key + 1 < sk) dm[1] = (uint8_t)rv1;
+                        }
                     }
             }
 
