@@ -90,7 +90,7 @@ struct BParams {
     float out_scale;       // softmax_scale: the factor of dQ and dK
     const float *alibi;
     int32_t alibi_bs;
-    // dropout (as KParams): keep iff fa_rand8 <= drop_thr (255 = off); every tile then takes the MASK form of the pointwise
+    // dropout (as KParams): keep iff the element's random byte <= drop_thr (255 = off)
     int32_t drop_thr;
     float rp_dropout;
     const uint64_t *rng_state;
@@ -232,17 +232,13 @@ __device__ __forceinline__ void bwd_point(const BParams &p, float x, float dp, f
     pv = __builtin_amdgcn_exp2f(sl);
     if constexpr (MASK) pv = visible ? pv : 0.f;
     bool keep = true;
-    if constexpr (MASK) {
-        if constexpr (DROPOUT) {  // O = (keep . P / (1 - p)) V: dP picks up the same factor, D = rowsum(dO . O) still holds
-            keep = rv <= (uint32_t)p.drop_thr;
-            dp = keep ? dp * p.rp_dropout : 0.f;
-        }
+    if constexpr (DROPOUT) {  // O = (keep . P / (1 - p)) V: dP picks up the same factor, D = rowsum(dO . O) still holds
+        keep = rv <= (uint32_t)p.drop_thr;
+        dp = keep ? dp * p.rp_dropout : 0.f;
     }
     ds = pv * (dp - dsum);
     if constexpr (SOFTCAP) ds *= (1.f - t * t);
-    if constexpr (MASK) {
-        if constexpr (DROPOUT) pv = keep ? pv * p.rp_dropout : 0.f;  // the P that multiplies dO in dV
-    }
+    if constexpr (DROPOUT) pv = keep ? pv * p.rp_dropout : 0.f;  // the P that multiplies dO in dV
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -459,7 +455,6 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_kernel(const BParams p) {
         bool need_mask = (key_w0 + WKEYS > sk) || (row0 + BM > sq);
         if (p.window_right >= 0) need_mask = need_mask || (key_w0 + WKEYS - 1 > row0 + shift + p.window_right);
         if (p.window_left >= 0) need_mask = need_mask || (key_w0 < row0 + BM - 1 + shift - p.window_left);
-        need_mask = need_mask || DROPOUT;
 
         if (!skip) {
 #pragma unroll
@@ -804,7 +799,6 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_kernel(const BParams p) {
         bool need_mask = (k0 + BLOCK_N > sk);
         if (p.window_right >= 0) need_mask = need_mask || (k0 + BLOCK_N - 1 > wrow + shift + p.window_right);
         if (p.window_left >= 0) need_mask = need_mask || (k0 < wrow + WROWS - 1 + shift - p.window_left);
-        need_mask = need_mask || DROPOUT;
 
         if (!skip) {
             const char *kbuf = smem + cur * TILE_BYTES;
