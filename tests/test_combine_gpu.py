@@ -19,9 +19,9 @@ def _fa3():
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("d", [64, 59, 128, 256, 512])
-@pytest.mark.parametrize("seqlen", [1, 3, 113, 640])
-@pytest.mark.parametrize("num_splits", [1, 2, 5, 17, 133])
+@pytest.mark.parametrize("d", [64, 59, 256, 512])
+@pytest.mark.parametrize("seqlen", [1, 113, 640])
+@pytest.mark.parametrize("num_splits", [1, 3, 17, 133])
 def test_flash_attn_combine(num_splits, seqlen, d, dtype):
     torch.random.manual_seed(1)
     batch_size, nheads = 5, 16

@@ -154,6 +154,8 @@ def test_dense_output(sq, sk, d, causal, dtype, mha_type):
     """Shape matrix in the style of tests/test_flash_attn.py:878-919 (batch 4 -> 2, heads 6)."""
     if mha_type != "mha" and (sq, sk) not in [(113, 203), (512, 512), (1023, 1024)]:
         pytest.skip("gqa/mqa on a subset of shapes")
+    if dtype == torch.float16 and sq >= 2048:
+        pytest.skip("fp16 on the CPU oracle is slow at this size (7-14 s per case); covered in bf16")
     fa = _api()
     torch.manual_seed(0)
     b, h = 2, 6
