@@ -6,8 +6,12 @@ over one batch of synthetic tensors already resident in HBM.  Default workload =
 (C2: batch 4, 16 heads, head dim 128, seq 8192, bf16, non-causal) per GPU; with N GPUs every rank runs
 its own batch shard (no collective on the data path: attention shards over batch) => weak scaling.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4]
-  N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c5] [--scaling weak|strong]
+  N>1: either under torchrun (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...
+  bench.py --gpus N: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the env), or plain `python bench.py --gpus N`:
+  the parent then starts the N ranks itself (fresh child processes, before it has touched the GPU) and relays rank 0's line.
+  --scaling strong (c5 only: BASELINE config 5 / SURVEY.md 8(d)): the global batch of 32 is split 32/N per GPU.
+  --dry-run: CPU rehearsal of the launch / rendezvous / timing / reporting logic (gloo, no kernel; "dry_run": true).
 
 Prints ONE JSON line on rank 0 with metric/value/unit (whole-job TFLOP/s), `roofline` (MFMA bound: the
 kernel's algorithmic FLOPs / its HIP-event duration vs the 2.5 PFLOP/s dense bf16 peak) and `cpu_baseline`
@@ -25,6 +29,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, MI355X_MICROARCH.md (256 CU x 4 SIMD x 1024 FLOP/clk x 2.4 GHz)
+C5_GLOBAL_BATCH = 32       # BASELINE config 5: global batch 32, strong-scaled over 1/2/4/8 GPUs
+C5_DTYPE = "fp8_e4m3 storage / bf16 MFMA"
 
 WORKLOADS = {
     # name: (description, batch, heads_q, heads_kv, seqlen, head_dim, causal, varlen lens or None)
@@ -62,22 +68,25 @@ def algorithmic_bytes(w):
     rows = sum(lens) if lens is not None else b * s
     if w[0].split()[1] == "backward":  # read Q,K,V,O,dO + LSE; write dQ,dK,dV (+ D written and read once)
         return 2 * (4 * rows * h * d + 4 * rows * hk * d) + 4 * rows * h * 3
+    if w[0].startswith("C5"):  # e4m3 Q, K, V (1 B/element), bf16 O, fp32 LSE
+        return rows * h * d + 2 * rows * hk * d + 2 * rows * h * d + 4 * rows * h
     return 2 * (2 * rows * h * d + 2 * rows * hk * d) + 4 * rows * h  # Q+O, K+V (bf16) + LSE (fp32)
 
 
 def measured_traffic(workload_key):
-    """HBM bytes per launch from the committed rocprofv3 PMC summary (profiles/rNN_traffic.json), newest round that
-    measured this workload; None when no counter pass has been committed for it."""
+    """(bytes, source): HBM bytes per launch from the committed rocprofv3 PMC summary (profiles/rNN_traffic.json), newest
+    round that measured this workload -- a counter pass of the same command, NOT a measurement of this run (PMC passes
+    need the profiler); (None, None) when no counter pass has been committed for it."""
     import glob
-    best = None
+    best, src = None, None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json"))):
         try:
             d = json.load(open(path))
         except Exception:
             continue
         if d.get("workload") == workload_key:
-            best = d.get("hbm_bytes_per_launch")
-    return best
+            best, src = d.get("hbm_bytes_per_launch"), "profiles/" + os.path.basename(path)
+    return best, src
 
 
 def make_inputs(w, device, seed):
@@ -136,6 +145,62 @@ def cpu_baseline(w, budget_s=20.0):
     }
 
 
+def dry_run(args, w, rank, world, dist, timing_group):
+    """CPU rehearsal (tests/test_bench_harness.py): same rendezvous, barriers, max-over-ranks timing and JSON line as the
+    real run; the step is a fixed host-side wait instead of the kernel (there is no CPU fallback of the product path)."""
+    import torch
+    for _ in range(args.warmup):
+        pass
+    if dist is not None:
+        dist.barrier(group=timing_group)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(1e-3)
+    if dist is not None:
+        dist.barrier(group=timing_group)
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=timing_group)
+        elapsed = float(t.item())
+    flops = flops_of(w)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "attn fwd TFLOPS (aggregate over GPUs; per-GPU in per_gpu) + %MFMA-peak, bf16 hdim128 seq8192",
+            "value": round(flops * world * args.steps / elapsed / 1e12, 2), "unit": "TFLOP/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "none (dry run)",
+            "data": "none", "dry_run": True,
+            "config": {"workload": w[0], "batch_per_gpu": w[1], "sharding": f"batch shard x{world}, no collective"},
+            "roofline": None, "cpu_baseline": None}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (this parent has made no
+    GPU call: it never imports torch), relay rank 0's stdout (the one JSON line), fail if any rank fails."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    if any(rcs):
+        print(f"bench.py: rank exit codes {rcs}", file=sys.stderr)
+        sys.exit(1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -144,26 +209,36 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))  # c2 = BASELINE metric config
+    ap.add_argument("--scaling", default="weak", choices=("weak", "strong"),
+                    help="strong: c5 only, global batch 32 split over the GPUs (BASELINE config 5)")
     ap.add_argument("--variant", type=int, default=0, help="kernel variant override (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-run", action="store_true", help="CPU rehearsal of launch/rendezvous/reporting (gloo, no kernel)")
     args = ap.parse_args()
+    if args.scaling == "strong" and args.workload != "c5":
+        ap.error("--scaling strong is defined for --workload c5 (global batch 32, BASELINE config 5)")
+    if args.scaling == "strong" and C5_GLOBAL_BATCH % args.gpus:
+        ap.error(f"--scaling strong: {C5_GLOBAL_BATCH} batches do not split over {args.gpus} GPUs")
 
-    import torch
-    import flash_attention_annotated_amd as fa
-    from flash_attention_annotated_amd import _lib
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 and world != args.gpus:
-        print(f"bench.py --gpus {args.gpus} must be launched with torch.distributed.run --nproc-per-node {args.gpus}",
-              file=sys.stderr)
+    if args.gpus != world:
+        print(f"bench.py --gpus {args.gpus} was launched with WORLD_SIZE={world}", file=sys.stderr)
         sys.exit(2)
-    if not torch.cuda.is_available():
+
+    import torch
+    if not args.dry_run and not torch.cuda.is_available():
         print("bench.py needs a GPU (the product path has no CPU fallback)", file=sys.stderr)
         sys.exit(2)
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    if args.dry_run:
+        device = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
     dist = None
     if world > 1 or os.environ.get("FA_BENCH_FORCE_DIST"):  # (the env switch rehearses this path on one GPU)
         import torch.distributed as dist
@@ -174,23 +249,36 @@ def main():
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group(backend="nccl", device_id=device)
-            dist.barrier()  # one collective over RCCL/xGMI: brings the communicator up outside the timed region
-            torch.cuda.synchronize()
-            # the timing bracket is a host-side barrier (gloo): attention shards over batch, there is no data-path
-            # collective, and a device-side barrier would add its own kernel + launch latency to the measured time
-            timing_group = dist.new_group(backend="gloo")
+            if args.dry_run:
+                dist.init_process_group(backend="gloo")
+                timing_group = dist.group.WORLD
+            else:
+                dist.init_process_group(backend="nccl", device_id=device)
+                dist.barrier()  # one collective over RCCL/xGMI: brings the communicator up outside the timed region
+                torch.cuda.synchronize()
+                # the timing bracket is a host-side barrier (gloo): attention shards over batch, there is no data-path
+                # collective, and a device-side barrier would add its own kernel + launch latency to the measured time
+                timing_group = dist.new_group(backend="gloo")
             dist.barrier(group=timing_group)
         finally:
             sys.stdout.flush()
             os.dup2(saved_stdout, 1)
             os.close(saved_stdout)
 
+    w = WORKLOADS[args.workload]
+    if args.scaling == "strong":  # this rank's share of the global batch
+        w = (w[0].replace("b4", f"b{C5_GLOBAL_BATCH // world} (global b{C5_GLOBAL_BATCH} / {world})"),
+             C5_GLOBAL_BATCH // world) + w[2:]
+    if args.dry_run:
+        return dry_run(args, w, rank, world, dist, timing_group if dist is not None else None)
+
+    import flash_attention_annotated_amd as fa
+    from flash_attention_annotated_amd import _lib
+
     lib = _lib.load()
     if args.variant:
         lib.fa_set_default_variant(args.variant)
 
-    w = WORKLOADS[args.workload]
     if args.workload == "decode":
         (q, k, v), extra = (None, None, None), {}
     else:
@@ -276,6 +364,7 @@ def main():
                          "note": "one step = append launch + attention launch (HIP events around both)"},
             "cpu_baseline": None}), flush=True)
     elif rank == 0:
+        traffic, traffic_src = measured_traffic(args.workload)
         out = {
             "metric": ("attn bwd TFLOPS (reference convention: 2.5 x forward FLOPs)" if args.workload.endswith("_bwd") else
                        "attn fwd TFLOPS (aggregate over GPUs; per-GPU in per_gpu) + %MFMA-peak, bf16 hdim128 seq8192"),
@@ -287,15 +376,15 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
-            "dtype": "fp8_e4m3 storage / bf16 MFMA" if args.workload == "c5" else "bf16",
+            "dtype": C5_DTYPE if args.workload == "c5" else "bf16",
             "data": "synthetic (torch.randn N(0,1), seed = rank)",
             "config": {"workload": w[0], "batch_per_gpu": w[1], "heads_q": w[2], "heads_kv": w[3], "seqlen": w[4],
                        "head_dim": w[5], "causal": w[6], "sharding": f"batch shard x{world}, no collective"},
             "roofline": {
                 "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": measured_traffic(args.workload),
+                "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "kernel_ms_avg": round(avg_kernel_ms, 4), "kernel_ms_median": round(kernel_ms[len(kernel_ms) // 2], 4),
                 "kernel_ms_min": round(kernel_ms[0], 4), "algorithmic_flops_per_launch": flops,
                 "algorithmic_bytes_per_launch": algorithmic_bytes(w),
