@@ -456,6 +456,13 @@ int fa_debug_read_timing(unsigned long long *dst, int n_wg) {
     return hipMemcpyFromSymbol(dst, HIP_SYMBOL(fa::fa_timing_buf), sizeof(unsigned long long) * 32 * n_wg) == hipSuccess ? 0 : -1;
 }
 #endif
+#ifdef FA_CYCLES
+// developer-only: copy the fast-loop cycle stamps of the last fwd_kernel_w64 launch (see fa_fwd_kernel_w64.h) to the host
+int fa_debug_read_cycles(unsigned long long *dst) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(fa::fa_cycle_buf), sizeof(unsigned long long) * 256 * 4 * 64) == hipSuccess ? 0 : -1;
+}
+#endif
 void fa_set_default_variant(int32_t variant) { g_default_variant.store(variant); }
 
 const char *fa_strerror(int status) {

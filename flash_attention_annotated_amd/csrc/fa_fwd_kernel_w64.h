@@ -23,6 +23,7 @@
 #pragma once
 
 #include "fa_fwd_kernel.h"
+#include "fa_fwd_loop_gen.h"
 
 #include <type_traits>
 
@@ -347,6 +348,18 @@ __device__ unsigned long long fa_timing_buf[32 * 4096];
 #define FA_T(i) do { if constexpr ((FA_TMASK >> (i)) & 1) ((unsigned long long *)(smem + 6 * BLOCK_N * D * 2 + 1024))[(threadIdx.x >> 6) * 8 + (i)] = wall_clock64(); } while (0)
 #else
 #define FA_T(i)
+#endif
+
+// Developer-only cycle stamps of the fast loop (never shipped: -DFA_CYCLES builds, tools/loop_cycles.py): each wave appends
+// s_memtime (shader clock) at every fast half-step entry and between its two phases -- up to 60 stamps -- plus the 100 MHz
+// wall clock at the first and last stamp (slots 62, 63), into spare LDS; copied to fa_cycle_buf[workgroup][wave][64] at
+// the end.  The stamp drains lgkmcnt (s_memtime returns through it), i.e. it perturbs the LDS prefetch by ~100 cycles.
+#ifdef FA_CYCLES
+__device__ unsigned long long fa_cycle_buf[256 * 4 * 64];
+#define FA_C() do { if (cyc_n < 60) { unsigned long long *cb_ = (unsigned long long *)(smem + 6 * BLOCK_N * D * 2 + 1024) + (threadIdx.x >> 6) * 64; \
+        if (cyc_n == 0) cb_[62] = __builtin_amdgcn_s_memrealtime(); cb_[cyc_n++] = __builtin_amdgcn_s_memtime(); cb_[63] = __builtin_amdgcn_s_memrealtime(); cb_[61] = cyc_n; } } while (0)
+#else
+#define FA_C()
 #endif
 
 template <typename T, int D, bool SOFTCAP>
@@ -716,6 +729,9 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     // Pipeline state at the boundary in front of half-step j (canonical naming):
     //   sbx = S_B(j) (masked, not yet exponentiated), pax = P_A(j), (m_a, l_a) through j, (m_b, l_b) through
     //   j-1, and O_A still owes the factor alpha_a when moved_a.
+#ifdef FA_CYCLES
+    int cyc_n = 0;
+#endif
     f32x16 sa, sbx, sby;
     u32x4 pax[2], pay[2], pb[2];
     float alpha_a = 1.f, alpha_b = 1.f;
@@ -820,6 +836,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
         };
         const float csc = csc_arg;  // wave-uniform, lives in an SGPR
 
+        FA_C();
         // ---------- phase 1: S(j+1) = K.Q^T on the matrix pipe || exp/sum/pack of B(j) on the VALU ----------
         // LDS fragments are fetched two slices (>= 128 cycles) ahead of the MFMA that consumes them; the first
         // two V^T fragments of phase 2 are fetched during the last two slices of phase 1.
@@ -859,6 +876,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
             l_b += ps0 + ps1;
         }
 
+        FA_C();
         // ---------- phase 2: O += V^T.P^T on the matrix pipe || exp/sum/pack of A(j+1) on the VALU ----------
         {
             constexpr int NSTEP = 2 * DBLOCKS;  // (db, st) steps, two MFMAs each
@@ -951,11 +969,65 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
             rowmax16(sbx, m_b, xa, xb);
             if (__any(!((half_swap_max(fmaxf(xa, xb)) - m_b) * csc_arg <= THR))) continue;  // (NaN from -inf - -inf: not safe)
         }
+        // The bulk of the sweep: the generated asm loop (fa_fwd_loop_gen.h), for every run of >= 2 mask-free tiles whose
+        // look-ahead LDS-DMA tiles (K tile n+3, V tile n+2) lie fully inside the sequence.  What it leaves (the last
+        // three or so mask-free tiles, whose look-ahead rows have to be clamped) goes through the C++ form below.
+        bool tripped = false;
+        if constexpr (D == 128 && !SOFTCAP && !(FA_ABLATE & 32)) {
+            const int n_cur = n_min + (j >> 1);
+            int count = (fast_last - j) >> 1;  // tiles jt = j, j + 2, .. with jt + 2 <= fast_last
+            // (the descriptors address bytes with 32 bits: longer sequences stay on the C++ form)
+            if (count >= 2 && (int64_t)sk * k_rs64 < (1ll << 30) && (int64_t)sk * v_rs64 < (1ll << 30)) {
+                auto make_desc = [&](const T *base, int64_t rs64) {
+                    const uint64_t b = (uint64_t)(uintptr_t)base;
+                    u32x4 dsc;
+                    dsc[0] = (uint32_t)b;
+                    dsc[1] = (uint32_t)(b >> 32) & 0xffffu;                           // stride 0: raw buffer
+                    dsc[2] = (uint32_t)(((int64_t)(sk - 1) * rs64 + min(p.d, D)) * 2);  // bytes to the end of the last valid row
+                    dsc[3] = 0x00020000u;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) dsc[i] = __builtin_amdgcn_readfirstlane(dsc[i]);
+                    return dsc;
+                };
+                const u32x4 kdesc = make_desc(kp, k_rs64), vdesc = make_desc(vp, v_rs64);
+                uint32_t koffb[LD_PER_THREAD], voffb[LD_PER_THREAD];
+#pragma unroll
+                for (int i = 0; i < LD_PER_THREAD; ++i) {
+                    koffb[i] = koff[i] - 1024u * i;
+                    voffb[i] = voff[i] - 1024u * i;
+                }
+                const uint32_t ktile = (uint32_t)(((n_cur + 3) * BLOCK_N - 32) * k_rs * 2);
+                const uint32_t vtile = (uint32_t)((n_cur + 2) * BLOCK_N * v_rs * 2);
+                const float csc = csc_arg;
+                int done = 0;
+                uint64_t redo = 0;
+#ifdef FA_CYCLES
+                unsigned long long *cb_ = (unsigned long long *)(smem + 6 * BLOCK_N * D * 2 + 1024) + (threadIdx.x >> 6) * 64;
+                cb_[40] = __builtin_amdgcn_s_memtime(); cb_[42] = __builtin_amdgcn_s_memrealtime(); cb_[44] = count;
+#endif
+                FastLoop128<T>::run(oa, ob, qa, qb, sa, sbx, sby, pax, pay, l_a, l_b, l_a_saved,
+                                    (m_a == -INFINITY ? 0.f : m_a) * csc, (m_b == -INFINITY ? 0.f : m_b) * csc, m_b,
+                                    (uint32_t)kbase, (uint32_t)vbase, koffb, voffb, csc, THR / csc, LIM, kdesc, vdesc,
+                                    ktile, vtile, (uint32_t)(BLOCK_N * k_rs * 2), (uint32_t)(BLOCK_N * v_rs * 2), lds0,
+                                    lds_wave, (j >> 1) % 3, count, done, redo);
+#ifdef FA_CYCLES
+                cb_[41] = __builtin_amdgcn_s_memtime(); cb_[43] = __builtin_amdgcn_s_memrealtime(); cb_[45] = done;
+#endif
+                j += done;
+                in_flight = 2 * LD_PER_THREAD;
+                redo_a = redo != 0;
+                if (count != 0) {  // a guard tripped: the next half-step is the generic path's
+                    tripped = true;
+                    if (done & 1) to_canonical_after_odd();
+                }
+            }
+        }
         // fast: up to three tiles (one turn of the LDS rings) per iteration; the first turn starts at the ring slot of
         // tile j/2 (`skip` slots are already behind us); every fast tile issues 2 LD_PER_THREAD LDS-DMA pieces, one per
         // slice of its first half-step
         int skip = (j >> 1) % 3;
-        while (tile_ok(j)) {
+        if constexpr (D != 128 || SOFTCAP || (FA_ABLATE & 32))
+        while (!tripped && tile_ok(j)) {
             const int n = n_min + (j >> 1) - skip;  // the tile in ring slot 0 of this turn
             int done = 0;        // half-steps completed in this iteration
             bool odd_exit = false, x = false, stop = false;
@@ -1038,6 +1110,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     // 8), i.e. behind the same L2.  Its Q rows are a cold, badly coalesced gather (~4 us: tools/wg_phases.py); touching one
     // dword of each of their cache lines here, with the whole epilogue (~3 us) in front of the end of this workgroup, turns
     // that into L2 hits.  The data lands in a 1 KiB dump area of LDS; dense batches only (no cu_seqlens lookups here).
+#ifndef FA_CYCLES
     if (!p.cu_seqlens_q && !p.seqused_q && p.num_splits <= 1 && p.q_row_stride < (1 << 20)) {
         const int wg2 = blockIdx.x + 256;
         const int slot2 = wg2 >> 3;
@@ -1057,6 +1130,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
             for (int line = 0; line < (D * 2) / 128; ++line) lds_dma_touch(dump, q2, off2 + line * 128);
         }
     }
+#endif
     drain_all();        // asm MFMA results -> VALU readers
     // lane constants are rebuilt from the lane id here: the ones computed in front of the main loop were spilled to
     // scratch by then, and every reload is a separately awaited memory round trip (tools/wg_phases.py: 3.3 us epilogue)
@@ -1107,6 +1181,11 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
         }
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the prefetch's LDS-DMA has landed before this workgroup's LDS is released
+#ifdef FA_CYCLES
+    __syncthreads();
+    if (blockIdx.x < 256)
+        fa_cycle_buf[blockIdx.x * 256 + threadIdx.x] = ((unsigned long long *)(smem + 6 * BLOCK_N * D * 2 + 1024))[threadIdx.x];
+#endif
 #ifdef FA_TIMING
     FA_T(6);
     __builtin_amdgcn_s_waitcnt(0x0F70);  // O stores of this wave retired
@@ -1121,7 +1200,9 @@ template <int D>
 constexpr int smem_bytes_w64() {
     constexpr int kv = 6 * BLOCK_N * D * 2;  // the K/V rings; the O staging of the epilogue (4 x 64 x (2 D + 16)) fits inside
     static_assert(kv >= 4 * 64 * (D * 2 + 16), "O staging must fit the K/V rings");
-#ifdef FA_TIMING
+#if defined(FA_CYCLES)
+    return kv + 1024 + 2048;  // + cycle stamps (the Q prefetch dump area is off in this build)
+#elif defined(FA_TIMING)
     return kv + 1024 + 256;  // + dump area of the Q prefetch + time stamps
 #else
     return kv + 1024;        // + dump area of the Q prefetch (4 waves x 256 B)

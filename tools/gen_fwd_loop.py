@@ -1,0 +1,336 @@
+#!/usr/bin/env python3
+"""Generator of flash_attention_annotated_amd/csrc/fa_fwd_loop_gen.h: the steady-state tile loop of fwd_kernel_w64 at
+head-dim tile 128 as ONE inline-asm block per element type, every register and every issue slot assigned here.
+
+Why generated asm: the wave is alone on its SIMD and issues in order, so whatever sits between two MFMAs is the schedule.
+The C++ form of the same loop (fast_half in fa_fwd_kernel_w64.h) spends ~4000 cycles per 64-key tile where the 64 MFMAs
+need 2048: hipcc's glue between the hand-written slices (state copies, wave-uniform branches, address arithmetic, M0
+save/restore around every LDS-DMA piece, asm-boundary pads) is issued serially with the matrix pipe idle
+(profiles/r2_loop_cycles.txt: the loop stripped of ALL VALU / LDS / DMA work still takes ~3000 cycles per tile).  Here a tile is:
+64 MFMAs, 32 softmax pair-slices, 48 LDS fragment reads with counted waits, 8 LDS-DMA pieces (2 instructions each), two guard
+checks, one barrier, 6 scalar instructions of loop control.
+
+Dataflow = fast_half's (see fa_fwd_kernel_w64.h): per 32-key half-step two phases
+    phase 1   MFMA: S_A(j+1), S_B(j+1) = K.Q^T             VALU: exp/sum/pack of S_B(j)       -> P_B(j)
+    phase 2   MFMA: O_A += V^T P_A(j), O_B += V^T P_B(j)    VALU: exp/sum/pack of S_A(j+1)     -> P_A(j+1)
+with the running maxima kept stale (guards: A by its partial row sums, B by a max look-ahead); any guard trip leaves the
+block with the pipeline state the generic C++ half-step expects.  K/V rings, tile shift, DMA distance and the
+one-barrier-per-tile protocol are unchanged, so waves may leave the block at different tiles (causal) and keep
+rendezvousing with the others from the C++ paths.
+
+Run:  python tools/gen_fwd_loop.py  (writes the header in place; tests/test_gen_loop.py checks the committed file is current)
+"""
+import os
+import sys
+
+D = 128
+ROWB = D * 2
+TILE = 64 * ROWB            # bytes of one K or V tile image
+KSTEPS = D // 16            # 8
+NSTEP = 2 * (D // 32)       # 8 (db, st) steps of the PV product
+LD = 4                      # LDS-DMA pieces per wave and tile
+
+# ---- register map (arch VGPRs) ----
+SA, SBX, SBY = 0, 16, 32
+PAX, PAY, PB = 48, 56, 64
+KF, VF = 72, 84             # 3 x 4 each
+KA, VA = 96, 104            # 8 + 8 LDS address registers
+KOFF, VOFF = 112, 116
+MCA, MCB, LA, LB0, LAS, MB = 120, 121, 122, 123, 124, 125
+T0, T1, PSA0, PSA1, NXA, NXB, TMP, LB1 = 126, 127, 128, 129, 130, 131, 132, 133
+KBASE, VBASE = 134, 135
+# ---- AGPRs ----
+OA, OB, QA, QB = 0, 64, 128, 160
+
+
+def v(i, n=1):
+    return f"v{i}" if n == 1 else f"v[{i}:{i + n - 1}]"
+
+
+def a(i, n=1):
+    return f"a{i}" if n == 1 else f"a[{i}:{i + n - 1}]"
+
+
+class Emitter:
+    def __init__(self, mfma, cvt):
+        self.lines = []
+        self.mfma = mfma
+        self.cvt = cvt          # function (dst, t0, t1) -> list of instructions
+        self.lds_q = []         # outstanding LDS reads (tags), oldest first
+
+    def e(self, s):
+        self.lines.append(s)
+
+    def label(self, name):
+        self.lines.append(f"{name}:")
+
+    # --- LDS reads with counted waits ---
+    def ds_k(self, dst, ks, off, tag):
+        self.e(f"ds_read_b128 {v(dst, 4)}, {v(KA + ks)} offset:{off}")
+        self.lds_q.append(tag)
+
+    def ds_v(self, dst, db, st, off, tag):
+        for j2 in range(2):
+            self.e(f"ds_read_b64_tr_b16 {v(dst + 2 * j2, 2)}, {v(VA + 2 * db + j2)} offset:{off + (16 * st + 8 * j2) * ROWB}")
+            self.lds_q.append(tag)
+
+    def wait_for(self, tag):
+        """s_waitcnt lgkmcnt(N) such that every read tagged `tag` has returned (LDS returns in order)."""
+        idx = [i for i, t in enumerate(self.lds_q) if t == tag]
+        if not idx:
+            return
+        last = idx[-1]
+        n = len(self.lds_q) - 1 - last
+        self.e(f"s_waitcnt lgkmcnt({n})")
+        self.lds_q = self.lds_q[last + 1:]
+
+    def wait_all(self):
+        self.lds_q = []
+
+
+def cvt_bf16(dst, t0, t1):
+    return [f"v_cvt_pk_bf16_f32 {v(dst)}, {v(t0)}, {v(t1)}"]
+
+
+def cvt_f16(dst, t0, t1):
+    return [f"v_cvt_f16_f32 {v(dst)}, {v(t0)}",
+            f"v_cvt_f16_f32_sdwa {v(dst)}, {v(t1)} dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD"]
+
+
+def gen_half(E, slot, KB, uid):
+    """One 32-key half-step of the tile in ring slot `slot`."""
+    sb_cur, sb_nxt = (SBX, SBY) if KB == 0 else (SBY, SBX)
+    pa_cur, pa_nxt = (PAX, PAY) if KB == 0 else (PAY, PAX)
+    kb_off = ((slot + 1) % 3) * TILE + KB * 32 * ROWB     # K rows of the scores of half-step j+1
+    vb_off = slot * TILE + KB * 32 * ROWB                  # V rows of half-step j (VA carries the V region base)
+    kdst = slot * TILE                                     # LDS-DMA targets of this tile: K tile n+3 -> K ring slot `slot`,
+    vdst = (3 + (slot + 2) % 3) * TILE                     #                               V tile n+2 -> V ring slot (slot+2)%3
+    kf = lambda i: KF + 4 * (i % 3)
+    vf = lambda i: VF + 4 * (i % 3)
+    mf = E.mfma
+    E.e(f"; ---- slot {slot} half-step KB={KB}: phase 1")
+    for ks in range(KSTEPS):
+        # LDS fragment fetch two slices ahead
+        if ks + 2 < KSTEPS:
+            E.ds_k(kf(ks + 2), ks + 2, kb_off, ("k", uid, ks + 2))
+        elif ks + 2 == KSTEPS:
+            E.ds_v(vf(0), 0, 0, vb_off, ("v", uid, 0))
+        else:
+            E.ds_v(vf(1), 0, 1, vb_off, ("v", uid, 1))
+        if KB == 0 and ks == 0:
+            E.e(f"s_add_u32 m0, %[lds_wave], {kdst}")
+        E.wait_for(("k", uid, ks))
+        c_a = "0" if ks == 0 else v(SA, 16)
+        c_b = "0" if ks == 0 else v(sb_nxt, 16)
+        E.e(f"{mf} {v(SA, 16)}, {v(kf(ks), 4)}, %[qa{ks}], {c_a}")
+        if KB == 0 and ks < LD:
+            # piece ks of K tile n+3: 1 KiB at M0 + 1024 ks (the instruction offset moves the LDS target AND the source: the
+            # lane offsets carry -1024 ks); rows past the end of the sequence read as zeros (raw buffer, num_records)
+            E.e(f"buffer_load_dwordx4 {v(KOFF + ks)}, %[kdesc], %[ktile] offen offset:{1024 * ks} lds")
+        s0, s1 = sb_cur + 2 * ks, sb_cur + 2 * ks + 1
+        E.e(f"v_fma_f32 {v(T0)}, {v(s0)}, %[csc], -{v(MCB)}")
+        E.e(f"v_fma_f32 {v(T1)}, {v(s1)}, %[csc], -{v(MCB)}")
+        E.e(f"v_exp_f32 {v(T0)}, {v(T0)}")
+        E.e(f"v_exp_f32 {v(T1)}, {v(T1)}")
+        E.e(f"{mf} {v(sb_nxt, 16)}, {v(kf(ks), 4)}, %[qb{ks}], {c_b}")
+        E.e(f"v_add_f32 {v(LB0)}, {v(LB0)}, {v(T0)}")
+        E.e(f"v_add_f32 {v(LB1)}, {v(LB1)}, {v(T1)}")
+        for ins in E.cvt(PB + ks, T0, T1):
+            E.e(ins)
+    if KB == 0:  # K source of the next tile's DMA
+        E.e("s_add_u32 %[ktile], %[ktile], %[kstep]")
+    E.e(f"; ---- slot {slot} half-step KB={KB}: phase 2")
+    E.e(f"v_mov_b32 {v(PSA0)}, 0")
+    E.e(f"v_mov_b32 {v(PSA1)}, 0")
+    for t in range(NSTEP):
+        db, st = t >> 1, t & 1
+        if KB == 1 and t == NSTEP - 2:
+            # tile barrier, two slices early: every K/V read of this tile has been issued; the DMA pieces issued one tile ago
+            # (all but this tile's 2 LD youngest) have landed.  Behind it the next tile's first K fragments are fetched
+            # under the last two slices' MFMAs.
+            E.e(f"s_waitcnt vmcnt({2 * LD}) lgkmcnt(0)")
+            E.wait_all()
+            E.e("s_barrier")
+        if t + 2 < NSTEP:
+            E.ds_v(vf(t + 2), (t + 2) >> 1, (t + 2) & 1, vb_off, ("v", uid, t + 2))
+        else:
+            nks = t + 2 - NSTEP  # first two K fragments of the next half-step
+            if KB == 0:
+                E.ds_k(kf(nks), nks, kb_off + 32 * ROWB, ("k", uid + 1, nks))
+            else:
+                E.ds_k(kf(nks), nks, ((slot + 2) % 3) * TILE, ("k", uid + 1, nks))
+        if KB == 0 and t == 0:
+            E.e(f"s_add_u32 m0, %[lds_wave], {vdst}")
+        E.wait_for(("v", uid, t))
+        E.e(f"{mf} %[oa{db}], {v(vf(t), 4)}, {v(pa_cur + 4 * st, 4)}, %[oa{db}]")
+        if KB == 0 and t < LD:
+            E.e(f"buffer_load_dwordx4 {v(VOFF + t)}, %[vdesc], %[vtile] offen offset:{1024 * t} lds")
+        s0, s1 = SA + 2 * t, SA + 2 * t + 1
+        E.e(f"v_fma_f32 {v(T0)}, {v(s0)}, %[csc], -{v(MCA)}")
+        E.e(f"v_fma_f32 {v(T1)}, {v(s1)}, %[csc], -{v(MCA)}")
+        E.e(f"v_exp_f32 {v(T0)}, {v(T0)}")
+        E.e(f"v_exp_f32 {v(T1)}, {v(T1)}")
+        E.e(f"{mf} %[ob{db}], {v(vf(t), 4)}, {v(PB + 4 * st, 4)}, %[ob{db}]")
+        E.e(f"v_add_f32 {v(PSA0)}, {v(PSA0)}, {v(T0)}")
+        E.e(f"v_add_f32 {v(PSA1)}, {v(PSA1)}, {v(T1)}")
+        for ins in E.cvt(pa_nxt + t, T0, T1):
+            E.e(ins)
+        # look-ahead max of S_B(j+1) (complete since the end of phase 1), two v_max3 per slice over slices 2..5
+        if 2 <= t <= 5:
+            i = (t - 2) * 4
+            first = (t == 2)
+            E.e(f"v_max3_f32 {v(NXA)}, {v(sb_nxt + i)}, {v(sb_nxt + i + 1)}, {v(MB) if first else v(NXA)}")
+            E.e(f"v_max3_f32 {v(NXB)}, {v(sb_nxt + i + 2)}, {v(sb_nxt + i + 3)}, {v(MB) if first else v(NXB)}")
+    if KB == 0:
+        E.e("s_add_u32 %[vtile], %[vtile], %[vstep]")
+    # ---- guards (rare exits).  Spacing: >= 2 instructions between a VALU write and the permlane that reads it, one
+    #      instruction between a v_cmp and the SALU reader of vcc ----
+    E.e(f"v_add_f32 {v(TMP)}, {v(PSA0)}, {v(PSA1)}")
+    E.e(f"v_max_f32 {v(NXA)}, {v(NXA)}, {v(NXB)}")
+    E.e(f"v_mov_b32 {v(LAS)}, {v(LA)}")
+    E.e(f"v_mov_b32 {v(NXB)}, {v(NXA)}")
+    E.e(f"v_cmp_nge_f32 vcc, %[lim], {v(TMP)}")          # !(ps <= LIM): P_A(j+1) outgrew the stale max (or inf / NaN)
+    E.e(f"v_add_f32 {v(LA)}, {v(LA)}, {v(TMP)}")
+    E.e("s_mov_b64 %[redo], vcc")
+    E.e(f"v_permlane32_swap_b32 {v(NXA)}, {v(NXB)}")
+    E.e(f"v_max_f32 {v(NXA)}, {v(NXA)}, {v(NXB)}")
+    E.e(f"v_sub_f32 {v(NXA)}, {v(NXA)}, {v(MB)}")
+    E.e(f"v_cmp_nge_f32 vcc, %[thr_c], {v(NXA)}")        # !((m_new_b - m_b) <= THR / c)
+    E.e("s_add_u32 %[done], %[done], 1")
+    E.e("s_or_b64 vcc, vcc, %[redo]")
+    E.e(f"s_cbranch_vccnz .Lfa_exit_{'%='}")
+
+
+def gen_block(mfma, cvt):
+    E = Emitter(mfma, cvt)
+    u = "%="
+    E.e("s_mov_b32 %[m0save], m0")
+    # LDS address registers: K fragment ks = lds0 + (kbase ^ 32 ks); V^T fragment (db, j2) = lds0 + 3 TILE + (vbase ^ (64 db + 32 j2))
+    for ks in range(KSTEPS):
+        E.e(f"v_xor_b32 {v(KA + ks)}, {32 * ks}, {v(KBASE)}")
+    for db in range(D // 32):
+        for j2 in range(2):
+            E.e(f"v_xor_b32 {v(VA + 2 * db + j2)}, {64 * db + 32 * j2}, {v(VBASE)}")
+    for i in range(8):
+        E.e(f"v_add_u32 {v(KA + i)}, %[lds0], {v(KA + i)}")
+        E.e(f"v_add_u32 {v(VA + i)}, %[lds0v], {v(VA + i)}")
+    E.e(f"v_mov_b32 {v(LB1)}, 0")
+    # entry: first two K fragments of the first half-step, from K ring slot (slot0 + 1) % 3
+    E.e("s_cmp_eq_u32 %[slot0], 1")
+    E.e(f"s_cbranch_scc1 .Lfa_in1_{u}")
+    E.e("s_cmp_eq_u32 %[slot0], 2")
+    E.e(f"s_cbranch_scc1 .Lfa_in2_{u}")
+    for s in range(3):
+        if s:
+            E.label(f".Lfa_in{s}_{u}")
+        E.lds_q = []
+        E.ds_k(KF, 0, ((s + 1) % 3) * TILE, ("k", 1000 + 2 * s, 0))
+        E.ds_k(KF + 4, 1, ((s + 1) % 3) * TILE, ("k", 1000 + 2 * s, 1))
+        E.e(f"s_branch .Lfa_t{s}_{u}")
+    uid = 1000
+    for s in range(3):
+        E.label(f".Lfa_t{s}_{u}")
+        E.lds_q = [("k", 1000 + 2 * s, 0), ("k", 1000 + 2 * s, 1)]
+        gen_half(E, s, 0, 1000 + 2 * s)
+        gen_half(E, s, 1, 1000 + 2 * s + 1)
+        # (the K fragments fetched at the end of KB = 1 carry uid 1000 + 2 s + 2 = the next slot's KB = 0 tags; for slot 2 they
+        #  wrap to slot 0's)
+        E.e("s_sub_u32 %[count], %[count], 1")
+        E.e("s_cmp_eq_u32 %[count], 0")
+        E.e(f"s_cbranch_scc1 .Lfa_exit_{u}")
+        if s == 2:
+            E.e(f"s_branch .Lfa_t0_{u}")
+    E.label(f".Lfa_exit_{u}")
+    E.e("s_waitcnt lgkmcnt(0)")
+    E.e(f"v_add_f32 {v(LB0)}, {v(LB0)}, {v(LB1)}")
+    E.e("s_nop 15")
+    E.e("s_nop 7")   # asm MFMA results -> compiler-visible readers
+    E.e("s_mov_b32 m0, %[m0save]")
+    return E.lines
+
+
+HEADER = '''// GENERATED by tools/gen_fwd_loop.py -- do not edit; regenerate with `python tools/gen_fwd_loop.py`.
+//
+// fa::FastLoop128<T>::run: the steady-state tile loop of fwd_kernel_w64 (head-dim tile 128) as one inline-asm block with
+// every register assigned (see the generator's docstring for the why and the dataflow).  Register map:
+//   O_A / O_B (8 x 16) and the Q fragments (16 x 4): AGPR tuples wherever hipcc keeps them (asm operands)
+//   v[0:15] S_A  v[16:31] S_B (even half-steps)  v[32:47] S_B (odd)  v[48:55] P_A (even)  v[56:63] P_A (odd)  v[64:71] P_B
+//   v[72:83] K fragment ring  v[84:95] V^T fragment ring  v[96:111] LDS address registers  v[112:119] LDS-DMA lane offsets
+//   v120 m_a c  v121 m_b c  v122 l_a  v123 l_b  v124 l_a before the last half-step  v125 m_b  v[126:133] temporaries
+// On return: `done` half-steps were completed (an odd count leaves the next scores / P_A in sby / pay: the caller's
+// to_canonical_after_odd()), `redo` != 0 means P_A of the next half-step must be redone from sa with a fresh max, and the
+// LDS-DMA pieces of the last tile started are in flight exactly as after the C++ fast loop.
+// K/V tiles arrive by `buffer_load_dwordx4 ... offen lds` through raw buffer descriptors (kdesc / vdesc: base = first row
+// of this (batch, kv head), num_records = bytes up to the end of the last valid row): rows past the end of the sequence
+// land as zeros, so look-ahead tiles need no clamping; ktile / vtile are the byte offsets of the next tiles to fetch
+// (soffset), koff / voff the lane offsets minus 1024 per piece (the instruction offset that steps the LDS target also
+// enters the source address; tools/probe_bufload.hip, profiles/r2_probe_bufload.txt).
+#pragma once
+
+namespace fa {
+
+template <typename T> struct FastLoop128;
+'''
+
+FUNC = '''template <> struct FastLoop128<%(T)s> {
+    static __device__ __forceinline__ void run(f32x16 (&oa)[4], f32x16 (&ob)[4], u32x4 (&qa)[8], u32x4 (&qb)[8], f32x16 &sa,
+                                               f32x16 &sbx, f32x16 &sby, u32x4 (&pax)[2], u32x4 (&pay)[2], float &l_a, float &l_b,
+                                               float &l_a_saved, float mca, float mcb, float m_b, uint32_t kbase, uint32_t vbase,
+                                               const uint32_t (&koff)[4], const uint32_t (&voff)[4], float csc, float thr_c,
+                                               float lim, u32x4 kdesc, u32x4 vdesc, uint32_t ktile, uint32_t vtile,
+                                               uint32_t kstep, uint32_t vstep, uint32_t lds0, uint32_t lds_wave, int slot0,
+                                               int &count, int &done, uint64_t &redo) {
+        uint32_t m0save;
+        const uint32_t lds0v = lds0 + %(vregion)d;
+        asm volatile(
+%(body)s
+            : [oa0] "+a"(oa[0]), [oa1] "+a"(oa[1]), [oa2] "+a"(oa[2]), [oa3] "+a"(oa[3]),
+              [ob0] "+a"(ob[0]), [ob1] "+a"(ob[1]), [ob2] "+a"(ob[2]), [ob3] "+a"(ob[3]),
+              [qa0] "+a"(qa[0]), [qa1] "+a"(qa[1]), [qa2] "+a"(qa[2]), [qa3] "+a"(qa[3]),
+              [qa4] "+a"(qa[4]), [qa5] "+a"(qa[5]), [qa6] "+a"(qa[6]), [qa7] "+a"(qa[7]),
+              [qb0] "+a"(qb[0]), [qb1] "+a"(qb[1]), [qb2] "+a"(qb[2]), [qb3] "+a"(qb[3]),
+              [qb4] "+a"(qb[4]), [qb5] "+a"(qb[5]), [qb6] "+a"(qb[6]), [qb7] "+a"(qb[7]),
+              "+{v[0:15]}"(sa), "+{v[16:31]}"(sbx), "+{v[32:47]}"(sby),
+              "+{v[48:51]}"(pax[0]), "+{v[52:55]}"(pax[1]), "+{v[56:59]}"(pay[0]), "+{v[60:63]}"(pay[1]),
+              "+{v122}"(l_a), "+{v123}"(l_b), "+{v124}"(l_a_saved),
+              [ktile] "+s"(ktile), [vtile] "+s"(vtile),
+              [count] "+s"(count), [done] "+s"(done), [redo] "=&s"(redo), [m0save] "=&s"(m0save)
+            : "{v120}"(mca), "{v121}"(mcb), "{v125}"(m_b), "{v134}"(kbase), "{v135}"(vbase),
+              "{v112}"(koff[0]), "{v113}"(koff[1]), "{v114}"(koff[2]), "{v115}"(koff[3]),
+              "{v116}"(voff[0]), "{v117}"(voff[1]), "{v118}"(voff[2]), "{v119}"(voff[3]),
+              [csc] "s"(csc), [thr_c] "s"(thr_c), [lim] "s"(lim), [kstep] "s"(kstep), [vstep] "s"(vstep),
+              [kdesc] "s"(kdesc), [vdesc] "s"(vdesc),
+              [lds0] "s"(lds0), [lds0v] "s"(lds0v), [lds_wave] "s"(lds_wave), [slot0] "s"(slot0)
+            : "memory", "vcc", "scc"%(clobbers)s);
+    }
+};
+'''
+
+
+def render(lines):
+    out = []
+    for l in lines:
+        if l.endswith(":"):
+            out.append(f'            "{l}\\n"')
+        else:
+            out.append(f'            "{l}\\n\\t"')
+    return "\n".join(out)
+
+
+def main():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "flash_attention_annotated_amd", "csrc", "fa_fwd_loop_gen.h")
+    clob = "".join(f', "v{i}"' for i in list(range(64, 112)) + list(range(126, 134)))
+    text = HEADER
+    for T, mf, cvt in (("__bf16", "v_mfma_f32_32x32x16_bf16", cvt_bf16), ("_Float16", "v_mfma_f32_32x32x16_f16", cvt_f16)):
+        lines = gen_block(mf, cvt)
+        text += "\n" + FUNC % {"T": T, "body": render(lines), "clobbers": clob, "vregion": 3 * TILE}
+    text += "\n}  // namespace fa\n"
+    if "--check" in sys.argv:
+        sys.exit(0 if os.path.exists(path) and open(path).read() == text else 1)
+    open(path, "w").write(text)
+    print(f"wrote {path}: {text.count(chr(10))} lines")
+
+
+if __name__ == "__main__":
+    main()
