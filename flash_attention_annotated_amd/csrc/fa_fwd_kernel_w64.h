@@ -23,7 +23,11 @@
 #pragma once
 
 #include "fa_fwd_kernel.h"
+#ifdef FA_LOOP_GEN_HEADER  /* developer-only: a timing-ablation variant of the generated loop */
+#include FA_LOOP_GEN_HEADER
+#else
 #include "fa_fwd_loop_gen.h"
+#endif
 
 #include <type_traits>
 

@@ -29,6 +29,9 @@ TILE = 64 * ROWB            # bytes of one K or V tile image
 KSTEPS = D // 16            # 8
 NSTEP = 2 * (D // 32)       # 8 (db, st) steps of the PV product
 LD = 4                      # LDS-DMA pieces per wave and tile
+# developer-only timing ablations (results are WRONG when non-zero; `--ablate N --out path`, never committed):
+# 1 no LDS-DMA, 2 no guard checks, 4 no max look-ahead, 8 no softmax VALU, 16 no barrier
+ABLATE = 0
 
 # ---- register map (arch VGPRs) ----
 SA, SBX, SBY = 0, 16, 32
@@ -38,7 +41,7 @@ KA, VA = 96, 104            # 8 + 8 LDS address registers
 KOFF, VOFF = 112, 116
 MCA, MCB, LA, LB0, LAS, MB = 120, 121, 122, 123, 124, 125
 T0, T1, PSA0, PSA1, NXA, NXB, TMP, LB1 = 126, 127, 128, 129, 130, 131, 132, 133
-KBASE, VBASE = 134, 135
+KBASE, VBASE, MBT = 134, 135, 136
 # ---- AGPRs ----
 OA, OB, QA, QB = 0, 64, 128, 160
 
@@ -123,20 +126,22 @@ def gen_half(E, slot, KB, uid):
         c_a = "0" if ks == 0 else v(SA, 16)
         c_b = "0" if ks == 0 else v(sb_nxt, 16)
         E.e(f"{mf} {v(SA, 16)}, {v(kf(ks), 4)}, %[qa{ks}], {c_a}")
-        if KB == 0 and ks < LD:
+        if KB == 0 and ks < LD and not (ABLATE & 1):
             # piece ks of K tile n+3: 1 KiB at M0 + 1024 ks (the instruction offset moves the LDS target AND the source: the
             # lane offsets carry -1024 ks); rows past the end of the sequence read as zeros (raw buffer, num_records)
             E.e(f"buffer_load_dwordx4 {v(KOFF + ks)}, %[kdesc], %[ktile] offen offset:{1024 * ks} lds")
         s0, s1 = sb_cur + 2 * ks, sb_cur + 2 * ks + 1
-        E.e(f"v_fma_f32 {v(T0)}, {v(s0)}, %[csc], -{v(MCB)}")
-        E.e(f"v_fma_f32 {v(T1)}, {v(s1)}, %[csc], -{v(MCB)}")
-        E.e(f"v_exp_f32 {v(T0)}, {v(T0)}")
-        E.e(f"v_exp_f32 {v(T1)}, {v(T1)}")
+        if not (ABLATE & 8):
+            E.e(f"v_fma_f32 {v(T0)}, {v(s0)}, %[csc], -{v(MCB)}")
+            E.e(f"v_fma_f32 {v(T1)}, {v(s1)}, %[csc], -{v(MCB)}")
+            E.e(f"v_exp_f32 {v(T0)}, {v(T0)}")
+            E.e(f"v_exp_f32 {v(T1)}, {v(T1)}")
         E.e(f"{mf} {v(sb_nxt, 16)}, {v(kf(ks), 4)}, %[qb{ks}], {c_b}")
-        E.e(f"v_add_f32 {v(LB0)}, {v(LB0)}, {v(T0)}")
-        E.e(f"v_add_f32 {v(LB1)}, {v(LB1)}, {v(T1)}")
-        for ins in E.cvt(PB + ks, T0, T1):
-            E.e(ins)
+        if not (ABLATE & 8):
+            E.e(f"v_add_f32 {v(LB0)}, {v(LB0)}, {v(T0)}")
+            E.e(f"v_add_f32 {v(LB1)}, {v(LB1)}, {v(T1)}")
+            for ins in E.cvt(PB + ks, T0, T1):
+                E.e(ins)
     if KB == 0:  # K source of the next tile's DMA
         E.e("s_add_u32 %[ktile], %[ktile], %[kstep]")
     E.e(f"; ---- slot {slot} half-step KB={KB}: phase 2")
@@ -150,7 +155,8 @@ def gen_half(E, slot, KB, uid):
             # under the last two slices' MFMAs.
             E.e(f"s_waitcnt vmcnt({2 * LD}) lgkmcnt(0)")
             E.wait_all()
-            E.e("s_barrier")
+            if not (ABLATE & 16):
+                E.e("s_barrier")
         if t + 2 < NSTEP:
             E.ds_v(vf(t + 2), (t + 2) >> 1, (t + 2) & 1, vb_off, ("v", uid, t + 2))
         else:
@@ -163,41 +169,46 @@ def gen_half(E, slot, KB, uid):
             E.e(f"s_add_u32 m0, %[lds_wave], {vdst}")
         E.wait_for(("v", uid, t))
         E.e(f"{mf} %[oa{db}], {v(vf(t), 4)}, {v(pa_cur + 4 * st, 4)}, %[oa{db}]")
-        if KB == 0 and t < LD:
+        if KB == 0 and t < LD and not (ABLATE & 1):
             E.e(f"buffer_load_dwordx4 {v(VOFF + t)}, %[vdesc], %[vtile] offen offset:{1024 * t} lds")
         s0, s1 = SA + 2 * t, SA + 2 * t + 1
-        E.e(f"v_fma_f32 {v(T0)}, {v(s0)}, %[csc], -{v(MCA)}")
-        E.e(f"v_fma_f32 {v(T1)}, {v(s1)}, %[csc], -{v(MCA)}")
-        E.e(f"v_exp_f32 {v(T0)}, {v(T0)}")
-        E.e(f"v_exp_f32 {v(T1)}, {v(T1)}")
+        last = (t == NSTEP - 1) and not (ABLATE & 2)
+        if not (ABLATE & 8):
+            E.e(f"v_fma_f32 {v(T0)}, {v(s0)}, %[csc], -{v(MCA)}")
+            E.e(f"v_fma_f32 {v(T1)}, {v(s1)}, %[csc], -{v(MCA)}")
+            E.e(f"v_exp_f32 {v(T0)}, {v(T0)}")
+            E.e(f"v_exp_f32 {v(T1)}, {v(T1)}")
+        if last:
+            # guard B (look-ahead): some score of S_B(j+1) exceeds m_b + THR / c in ANY lane (each lane half holds its own
+            # 16 keys of the row: no cross-half max needed for a wave-wide "any")
+            E.e(f"v_max_f32 {v(NXA)}, {v(NXA)}, {v(NXB)}")
+            E.e(f"v_cmp_nge_f32 vcc, {v(MBT)}, {v(NXA)}")      # !(m_b + THR / c >= max)
         E.e(f"{mf} %[ob{db}], {v(vf(t), 4)}, {v(PB + 4 * st, 4)}, %[ob{db}]")
-        E.e(f"v_add_f32 {v(PSA0)}, {v(PSA0)}, {v(T0)}")
-        E.e(f"v_add_f32 {v(PSA1)}, {v(PSA1)}, {v(T1)}")
-        for ins in E.cvt(pa_nxt + t, T0, T1):
-            E.e(ins)
+        if not (ABLATE & 8):
+            E.e(f"v_add_f32 {v(PSA0)}, {v(PSA0)}, {v(T0)}")
+            E.e(f"v_add_f32 {v(PSA1)}, {v(PSA1)}, {v(T1)}")
+            if last:
+                E.e("s_mov_b64 %[bflag], vcc")
+                E.e(f"v_add_f32 {v(TMP)}, {v(PSA0)}, {v(PSA1)}")
+            for ins in E.cvt(pa_nxt + t, T0, T1):
+                E.e(ins)
         # look-ahead max of S_B(j+1) (complete since the end of phase 1), two v_max3 per slice over slices 2..5
-        if 2 <= t <= 5:
+        if 2 <= t <= 5 and not (ABLATE & 4):
             i = (t - 2) * 4
             first = (t == 2)
             E.e(f"v_max3_f32 {v(NXA)}, {v(sb_nxt + i)}, {v(sb_nxt + i + 1)}, {v(MB) if first else v(NXA)}")
             E.e(f"v_max3_f32 {v(NXB)}, {v(sb_nxt + i + 2)}, {v(sb_nxt + i + 3)}, {v(MB) if first else v(NXB)}")
     if KB == 0:
         E.e("s_add_u32 %[vtile], %[vtile], %[vstep]")
-    # ---- guards (rare exits).  Spacing: >= 2 instructions between a VALU write and the permlane that reads it, one
-    #      instruction between a v_cmp and the SALU reader of vcc ----
-    E.e(f"v_add_f32 {v(TMP)}, {v(PSA0)}, {v(PSA1)}")
-    E.e(f"v_max_f32 {v(NXA)}, {v(NXA)}, {v(NXB)}")
-    E.e(f"v_mov_b32 {v(LAS)}, {v(LA)}")
-    E.e(f"v_mov_b32 {v(NXB)}, {v(NXA)}")
+    # ---- guards (rare exits): guard A = the partial row sums of P_A(j+1) ----
+    E.e("s_add_u32 %[done], %[done], 1")
+    if ABLATE & 2:
+        return
     E.e(f"v_cmp_nge_f32 vcc, %[lim], {v(TMP)}")          # !(ps <= LIM): P_A(j+1) outgrew the stale max (or inf / NaN)
+    E.e(f"v_mov_b32 {v(LAS)}, {v(LA)}")
     E.e(f"v_add_f32 {v(LA)}, {v(LA)}, {v(TMP)}")
     E.e("s_mov_b64 %[redo], vcc")
-    E.e(f"v_permlane32_swap_b32 {v(NXA)}, {v(NXB)}")
-    E.e(f"v_max_f32 {v(NXA)}, {v(NXA)}, {v(NXB)}")
-    E.e(f"v_sub_f32 {v(NXA)}, {v(NXA)}, {v(MB)}")
-    E.e(f"v_cmp_nge_f32 vcc, %[thr_c], {v(NXA)}")        # !((m_new_b - m_b) <= THR / c)
-    E.e("s_add_u32 %[done], %[done], 1")
-    E.e("s_or_b64 vcc, vcc, %[redo]")
+    E.e("s_or_b64 vcc, vcc, %[bflag]")
     E.e(f"s_cbranch_vccnz .Lfa_exit_{'%='}")
 
 
@@ -256,7 +267,8 @@ HEADER = '''// GENERATED by tools/gen_fwd_loop.py -- do not edit; regenerate wit
 //   O_A / O_B (8 x 16) and the Q fragments (16 x 4): AGPR tuples wherever hipcc keeps them (asm operands)
 //   v[0:15] S_A  v[16:31] S_B (even half-steps)  v[32:47] S_B (odd)  v[48:55] P_A (even)  v[56:63] P_A (odd)  v[64:71] P_B
 //   v[72:83] K fragment ring  v[84:95] V^T fragment ring  v[96:111] LDS address registers  v[112:119] LDS-DMA lane offsets
-//   v120 m_a c  v121 m_b c  v122 l_a  v123 l_b  v124 l_a before the last half-step  v125 m_b  v[126:133] temporaries
+//   v120 m_a c  v121 m_b c  v122 l_a  v123 l_b  v124 l_a before the last half-step  v125 m_b  v136 m_b + THR / c
+//   v[126:133] temporaries
 // On return: `done` half-steps were completed (an odd count leaves the next scores / P_A in sby / pay: the caller's
 // to_canonical_after_odd()), `redo` != 0 means P_A of the next half-step must be redone from sa with a fresh max, and the
 // LDS-DMA pieces of the last tile started are in flight exactly as after the C++ fast loop.
@@ -281,6 +293,7 @@ FUNC = '''template <> struct FastLoop128<%(T)s> {
                                                uint32_t kstep, uint32_t vstep, uint32_t lds0, uint32_t lds_wave, int slot0,
                                                int &count, int &done, uint64_t &redo) {
         uint32_t m0save;
+        uint64_t bflag;
         const uint32_t lds0v = lds0 + %(vregion)d;
         asm volatile(
 %(body)s
@@ -294,11 +307,11 @@ FUNC = '''template <> struct FastLoop128<%(T)s> {
               "+{v[48:51]}"(pax[0]), "+{v[52:55]}"(pax[1]), "+{v[56:59]}"(pay[0]), "+{v[60:63]}"(pay[1]),
               "+{v122}"(l_a), "+{v123}"(l_b), "+{v124}"(l_a_saved),
               [ktile] "+s"(ktile), [vtile] "+s"(vtile),
-              [count] "+s"(count), [done] "+s"(done), [redo] "=&s"(redo), [m0save] "=&s"(m0save)
-            : "{v120}"(mca), "{v121}"(mcb), "{v125}"(m_b), "{v134}"(kbase), "{v135}"(vbase),
+              [count] "+s"(count), [done] "+s"(done), [redo] "=&s"(redo), [bflag] "=&s"(bflag), [m0save] "=&s"(m0save)
+            : "{v120}"(mca), "{v121}"(mcb), "{v125}"(m_b), "{v136}"(m_b + thr_c), "{v134}"(kbase), "{v135}"(vbase),
               "{v112}"(koff[0]), "{v113}"(koff[1]), "{v114}"(koff[2]), "{v115}"(koff[3]),
               "{v116}"(voff[0]), "{v117}"(voff[1]), "{v118}"(voff[2]), "{v119}"(voff[3]),
-              [csc] "s"(csc), [thr_c] "s"(thr_c), [lim] "s"(lim), [kstep] "s"(kstep), [vstep] "s"(vstep),
+              [csc] "s"(csc), [lim] "s"(lim), [kstep] "s"(kstep), [vstep] "s"(vstep),
               [kdesc] "s"(kdesc), [vdesc] "s"(vdesc),
               [lds0] "s"(lds0), [lds0v] "s"(lds0v), [lds_wave] "s"(lds_wave), [slot0] "s"(slot0)
             : "memory", "vcc", "scc"%(clobbers)s);
@@ -318,8 +331,12 @@ def render(lines):
 
 
 def main():
+    global ABLATE
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     path = os.path.join(root, "flash_attention_annotated_amd", "csrc", "fa_fwd_loop_gen.h")
+    if "--ablate" in sys.argv:
+        ABLATE = int(sys.argv[sys.argv.index("--ablate") + 1])
+        path = sys.argv[sys.argv.index("--out") + 1]
     clob = "".join(f', "v{i}"' for i in list(range(64, 112)) + list(range(126, 134)))
     text = HEADER
     for T, mf, cvt in (("__bf16", "v_mfma_f32_32x32x16_bf16", cvt_bf16), ("_Float16", "v_mfma_f32_32x32x16_f16", cvt_f16)):
