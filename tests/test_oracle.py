@@ -177,3 +177,25 @@ def test_oracle_combine_reproduces_reference(golden_grads):
     fin = ~torch.isinf(lse)
     assert torch.allclose(lse[fin], gold["lse"][fin], atol=1e-6, rtol=1e-6)
     assert (out[2, 3] == 0).all() and torch.isinf(lse[2, 3]).all()
+
+
+def test_row_subset_oracle_equals_full_oracle():
+    """tests/test_full_size_gpu.py evaluates the oracle for a sample of query rows with the causal mask passed as an
+    additive -inf bias.  That is bit-identical to the oracle's own causal path on those rows (out, and LSE), in the
+    fp32 and in the low-precision reordered flavour, for sq == sk and sq != sk."""
+    from oracle import attention_ref as oracle
+    import torch
+    torch.manual_seed(3)
+    for sq, sk in ((96, 96), (64, 131)):
+        q = torch.randn(2, sq, 4, 32, dtype=torch.bfloat16)
+        k = torch.randn(2, sk, 2, 32, dtype=torch.bfloat16)
+        v = torch.randn(2, sk, 2, 32, dtype=torch.bfloat16)
+        rows = [0, 1, 17, 40, sq - 1]
+        i = torch.tensor(rows).view(-1, 1)
+        j = torch.arange(sk).view(1, -1)
+        bias = torch.where(j <= i + sk - sq, 0.0, float("-inf")).view(1, 1, len(rows), sk)
+        for kw in (dict(), dict(upcast=False, reorder_ops=True)):
+            full, _, lse_full = oracle.attention_ref(q, k, v, causal=True, return_lse=True, **kw)
+            sub, _, lse_sub = oracle.attention_ref(q[:, rows], k, v, attn_bias=bias, return_lse=True, **kw)
+            assert torch.equal(sub, full[:, rows])
+            assert torch.equal(lse_sub, lse_full[:, :, rows])

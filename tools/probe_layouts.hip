@@ -147,6 +147,87 @@ void run_mfma() {
     CHECK(hipFree(d));
 }
 
+
+// ---- v_mfma_scale_f32_32x32x64_f8f6f4 (e4m3): A row / B col = lane & 31 and k = 32 (lane >> 5) + byte? ----
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+__device__ __forceinline__ f32x16 mfma32(u32x8 a, u32x8 b) {
+    f32x16 d;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t one = 0x7f7f7f7fu;
+    asm volatile("s_nop 7\n\tv_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, 0, %3, %3 op_sel_hi:[0,0,0]\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" : "=&v"(d) : "v"(a), "v"(b), "v"(one));
+#endif
+    return d;
+}
+__device__ __forceinline__ u32x8 fill32(bool all_ones, bool hot, int j) {
+    u32x8 f;
+    for (int w = 0; w < 8; ++w) {
+        uint32_t x = 0;
+        for (int e = 0; e < 4; ++e)
+            if (all_ones || (hot && (w * 4 + e) == j)) x |= 0x38u << (8 * e);
+        f[w] = x;
+    }
+    return f;
+}
+// out[(L * 32 + j) * 4 + {0: row of A(L,j) from the 32x32 C layout, 1: col of B(L,j), 2: (lane' & 31 == 0) partner lane + 64 j', 3: #matches}]
+__global__ void probe_mfma32(int *out) {
+    const int L = blockIdx.x, lane = threadIdx.x;
+    for (int j = 0; j < 32; ++j) {
+        int *o = out + (L * 32 + j) * 4;
+        {
+            const f32x16 d = mfma32(fill32(false, lane == L, j), fill32(true, false, 0));
+            for (int r = 0; r < 16; ++r)
+                if (d[r] != 0.f && (lane & 31) == 0) o[0] = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        }
+        {
+            const f32x16 d = mfma32(fill32(true, false, 0), fill32(false, lane == L, j));
+            if (d[0] != 0.f && lane < 32) o[1] = lane;
+        }
+        int matches = 0, first = -1;
+        for (int L2 = 0; L2 < 64; ++L2)
+            for (int j2 = 0; j2 < 32; ++j2) {
+                const f32x16 d = mfma32(fill32(false, lane == L, j), fill32(false, lane == L2, j2));
+                bool nz = false;
+                for (int r = 0; r < 16; ++r) nz = nz || d[r] != 0.f;
+                if (__any(nz)) {
+                    ++matches;
+                    if ((L2 & 31) == 0) first = L2 + 64 * j2;
+                }
+            }
+        if (lane == 0) { o[2] = first; o[3] = matches; }
+    }
+}
+void run_mfma32() {
+    int *d;
+    CHECK(hipMalloc(&d, 64 * 32 * 4 * sizeof(int)));
+    CHECK(hipMemset(d, 0xff, 64 * 32 * 4 * sizeof(int)));
+    probe_mfma32<<<64, 64>>>(d);
+    CHECK(hipDeviceSynchronize());
+    std::vector<int> h(64 * 32 * 4);
+    CHECK(hipMemcpy(h.data(), d, h.size() * sizeof(int), hipMemcpyDeviceToHost));
+    int bad_row = 0, bad_col = 0, bad_k = 0, bad_n = 0;
+    for (int L = 0; L < 64; ++L)
+        for (int j = 0; j < 32; ++j) {
+            const int *o = &h[(L * 32 + j) * 4];
+            const int k = o[2] < 0 ? -1 : 32 * ((o[2] & 63) >> 5) + (o[2] >> 6);
+            bad_row += o[0] != (L & 31);
+            bad_col += o[1] != (L & 31);
+            bad_k += k != 32 * (L >> 5) + j;
+            bad_n += o[3] != 32;
+        }
+    printf("== v_mfma_scale_f32_32x32x64_f8f6f4 (e4m3, unit scales): hypothesis A[row = L&31][k = 32 (L>>5) + j], B[k = 32 (L>>5) + j][col = L&31], C row = (r&3) + 8 (r>>2) + 4 (lane>>5):\n"
+           "   row mismatches %d, col mismatches %d, k mismatches %d, match-count != 32: %d\n", bad_row, bad_col, bad_k, bad_n);
+    if (bad_row || bad_col || bad_k || bad_n)
+        for (int L = 0; L < 64; ++L) {
+            printf("   L=%2d:", L);
+            for (int j = 0; j < 32; ++j) {
+                const int *o = &h[(L * 32 + j) * 4];
+                printf(" (r%d c%d k%d n%d)", o[0], o[1], o[2] < 0 ? -1 : 32 * ((o[2] & 63) >> 5) + (o[2] >> 6), o[3]);
+            }
+            printf("\n");
+        }
+    CHECK(hipFree(d));
+}
+
 template <int BITS>
 void run_tr() {
     uint32_t *d;
@@ -172,6 +253,7 @@ int main() {
     run_mfma<BF16_16>();
     run_mfma<FP8_16>();
     run_mfma<MX8_16>();
+    run_mfma32();
     run_tr<16>();
     run_tr<8>();
     return 0;
