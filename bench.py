@@ -30,7 +30,8 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, MI355X_MICROARCH.md (256 CU x 4 SIMD x 1024 FLOP/clk x 2.4 GHz)
 C5_GLOBAL_BATCH = 32       # BASELINE config 5: global batch 32, strong-scaled over 1/2/4/8 GPUs
-C5_DTYPE = "fp8_e4m3 storage / bf16 MFMA"
+C5_DTYPE = "fp8_e4m3 (both products on v_mfma_scale_f32_32x32x64_f8f6f4, unit scales; fp32 accumulate, bf16 out)"
+PEAK_FP8_TFLOPS = 5000.0   # dense fp8 peak of the block-scaled MFMA (2x bf16 per clock), MI355X_MICROARCH.md
 
 WORKLOADS = {
     # name: (description, batch, heads_q, heads_kv, seqlen, head_dim, causal, varlen lens or None)
@@ -47,7 +48,7 @@ WORKLOADS = {
     # appended in place; HBM-bound: the figure of merit is cache bytes read per second
     "decode": ("decode b32 hq32 hkv8 d128 cache 8192 bf16 (flash_attn_with_kvcache, 1 new row appended)", 32, 32, 8,
                8192, 128, False, None),
-    "c5": ("C5 fp8 e4m3 b4 h16 d128 s8192 non-causal (fp8 storage, exact bf16 expansion pass + bf16 MFMA)", 4, 16, 16,
+    "c5": ("C5 fp8 e4m3 b4 h16 d128 s8192 non-causal (native e4m3 MFMA, no expansion pass)", 4, 16, 16,
            8192, 128, False, None),
 }
 
@@ -365,6 +366,7 @@ def main():
             "cpu_baseline": None}), flush=True)
     elif rank == 0:
         traffic, traffic_src = measured_traffic(args.workload)
+        peak = PEAK_FP8_TFLOPS if args.workload == "c5" else PEAK_BF16_TFLOPS
         out = {
             "metric": ("attn bwd TFLOPS (reference convention: 2.5 x forward FLOPs)" if args.workload.endswith("_bwd") else
                        "attn fwd TFLOPS (aggregate over GPUs; per-GPU in per_gpu) + %MFMA-peak, bf16 hdim128 seq8192"),
@@ -383,8 +385,11 @@ def main():
             "config": {"workload": w[0], "batch_per_gpu": w[1], "heads_q": w[2], "heads_kv": w[3], "seqlen": w[4],
                        "head_dim": w[5], "causal": w[6], "sharding": f"batch shard x{world}, no collective"},
             "roofline": {
-                "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 4), "frac_of_bf16_peak": round(achieved / PEAK_BF16_TFLOPS, 4),
+                "instruction": ("v_mfma_scale_f32_32x32x64_f8f6f4 (e4m3, unit block scales)" if args.workload == "c5" else
+                                "v_mfma_f32_32x32x16_bf16"),
+                "traffic": traffic, "traffic_source": traffic_src,
                 "kernel_ms_avg": round(avg_kernel_ms, 4), "kernel_ms_median": round(kernel_ms[len(kernel_ms) // 2], 4),
                 "kernel_ms_min": round(kernel_ms[0], 4), "algorithmic_flops_per_launch": flops,
                 "algorithmic_bytes_per_launch": algorithmic_bytes(w),

@@ -171,7 +171,7 @@ class FaBwdParams(ctypes.Structure):
 def build(force=False, verbose=False):
     """Compile csrc/ for gfx950 into the in-tree shared library (hipcc cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, "fa_fwd_api.hip"), os.path.join(CSRC, "fa_bwd_api.hip")]
-    deps = srcs + [os.path.join(CSRC, "fa_fwd_kernel.h"), os.path.join(CSRC, "fa_fwd_kernel_w64.h"), os.path.join(CSRC, "fa_fwd_loop_gen.h"),
+    deps = srcs + [os.path.join(CSRC, "fa_fwd_kernel.h"), os.path.join(CSRC, "fa_fwd_kernel_w64.h"), os.path.join(CSRC, "fa_fwd_loop_gen.h"), os.path.join(CSRC, "fa_fwd_kernel_fp8.h"), os.path.join(CSRC, "fa_fwd_loop_fp8_gen.h"),
                    os.path.join(CSRC, "fa_bwd_kernel.h"), os.path.join(INCLUDE, "fa_fwd.h"),
                    os.path.join(INCLUDE, "fa_bwd.h")]
     if not force and os.path.exists(LIB_PATH):

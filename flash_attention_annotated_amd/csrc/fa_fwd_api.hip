@@ -6,6 +6,7 @@
 #include "fa_fwd.h"
 #include "fa_fwd_kernel.h"
 #include "fa_fwd_kernel_w64.h"
+#include "fa_fwd_kernel_fp8.h"
 
 #include <algorithm>
 #include <atomic>
@@ -200,6 +201,27 @@ Fp8Plan fp8_plan(const fa_fwd_params *p) {
 int head_dim_tile(int d);
 int block_m_of(int variant, int d);
 
+// fp8 inputs run natively (fa_fwd_kernel_fp8.h: e4m3 operands straight into the block-scaled MFMA, no expansion pass, no
+// workspace) for the shape BASELINE config 5 names -- head dim 128, dense or varlen, full / causal / right-window masks.  The
+// rest of the fp8 surface (other head dims, softcap, left windows) and an explicit kernel_variant take the exact
+// e4m3 -> bf16 expansion in front of the 16-bit kernels.
+bool fp8_native(const fa_fwd_params *p) {
+    if (p->dtype != FA_DTYPE_FP8_E4M3 || p->d != 128) return false;
+    const int variant = p->kernel_variant ? p->kernel_variant : g_default_variant.load();
+    if (variant != 0) return false;
+    if (p->softcap > 0.f || p->alibi_slopes || p->block_table || p->kv_batch_idx || p->leftpad_k || p->p_dropout > 0.f) return false;
+    if (p->window_size_left >= 0 && p->window_size_left < p->seqlen_k) return false;
+    const int64_t strides[] = {p->q_row_stride, p->q_head_stride, p->k_row_stride, p->k_head_stride, p->v_row_stride,
+                               p->v_head_stride, p->cu_seqlens_q ? 0 : p->q_batch_stride, p->cu_seqlens_q ? 0 : p->k_batch_stride,
+                               p->cu_seqlens_q ? 0 : p->v_batch_stride};
+    for (int64_t st : strides)
+        if (st % 16 != 0) return false;
+    const void *ptrs[] = {p->q, p->k, p->v};
+    for (const void *ptr : ptrs)
+        if (reinterpret_cast<uintptr_t>(ptr) % 16 != 0) return false;
+    return true;
+}
+
 // ---- split-KV plan (role of num_splits_heuristic / set_params_splitkv, csrc/flash_attn/flash_api.cpp:257-329) ---------
 // Only dense (non-varlen) 16-bit problems split.  Heuristic (num_splits == 0): split when the tiles leave most of the
 // 256 CUs idle, so that tiles x splits reaches ~2 workgroups per CU, with at least 4 key blocks (256 keys) per split.
@@ -208,7 +230,9 @@ int block_m_of(int variant, int d);
 //  * short dense query blocks (seqlen_q <= 128: decode steps, short prefill chunks) -> 4 waves x 32 rows (variant 2):
 //    a 256-row tile would leave 2-3 of its 4 waves without rows, and this shape fits two workgroups per CU
 //    (measured on decode b8 hq32/hkv8 cache 8192: 149 -> 59 us, b32: 255 -> 219 us).
+bool fp8_native(const fa_fwd_params *p);
 int effective_variant(const fa_fwd_params *p) {
+    if (fp8_native(p)) return 0;  // one shape: 4 waves x 64 rows
     int variant = p->kernel_variant ? p->kernel_variant : g_default_variant.load();
     if (variant < 0 || variant > 3) variant = 0;
     if (p->p_dropout > 0.f) return 1;  // dropout lives in the compiler-scheduled shape only
@@ -581,7 +605,7 @@ int64_t fa_fwd_workspace_size(const fa_fwd_params *p) {
     if (p->abi_version != FA_ABI_VERSION || p->struct_size != sizeof(fa_fwd_params)) return FA_ERR_BAD_ABI;
     if (p->b <= 0 || p->h <= 0 || p->h_k <= 0 || p->d <= 0 || p->seqlen_q < 0 || p->seqlen_k < 0) return FA_ERR_BAD_SHAPE;
     if (p->cu_seqlens_q && (p->total_q < 0 || p->total_k < 0)) return FA_ERR_BAD_SHAPE;
-    if (p->dtype == FA_DTYPE_FP8_E4M3) return fp8_plan(p).total;
+    if (p->dtype == FA_DTYPE_FP8_E4M3) return fp8_native(p) ? 0 : fp8_plan(p).total;
     return split_plan(p, effective_variant(p)).total;
 }
 
@@ -618,7 +642,7 @@ int fa_fwd_validate(const fa_fwd_params *p) {
     const void *ptrs[] = {p->q, p->k, p->v, p->o};
     for (const void *ptr : ptrs)
         if (reinterpret_cast<uintptr_t>(ptr) % (fp8 && ptr != p->o ? 8 : 16) != 0) return FA_ERR_BAD_STRIDE;
-    if (fp8 && !empty && p->seqlen_k > 0) {
+    if (fp8 && !fp8_native(p) && !empty && p->seqlen_k > 0) {
         if (!p->workspace || reinterpret_cast<uintptr_t>(p->workspace) % 256 != 0 ||
             (int64_t)p->workspace_bytes < fp8_plan(p).total)
             return FA_ERR_WORKSPACE;
@@ -665,7 +689,8 @@ int fa_fwd(const fa_fwd_params *p, void *stream_) {
     const bool fp8 = p->dtype == FA_DTYPE_FP8_E4M3;
     const bool nothing = p->seqlen_q == 0 || p->seqlen_k == 0 || (p->cu_seqlens_q && p->total_q == 0);
     int64_t ws_q_row = 0, ws_k_row = 0;
-    if (fp8 && !nothing) {
+    const bool native8 = fp8 && fp8_native(p);
+    if (fp8 && !native8 && !nothing) {
         const Fp8Plan pl = fp8_plan(p);
         char *ws = static_cast<char *>(p->workspace);
         const int rpb_q = p->cu_seqlens_q ? 0 : p->seqlen_q, rpb_k = p->cu_seqlens_q ? 0 : p->seqlen_k;
@@ -689,10 +714,12 @@ int fa_fwd(const fa_fwd_params *p, void *stream_) {
     kp.q_batch_stride = p->q_batch_stride; kp.q_row_stride = p->q_row_stride; kp.q_head_stride = p->q_head_stride;
     kp.k_batch_stride = p->k_batch_stride; kp.k_row_stride = p->k_row_stride; kp.k_head_stride = p->k_head_stride;
     kp.v_batch_stride = p->v_batch_stride; kp.v_row_stride = p->v_row_stride; kp.v_head_stride = p->v_head_stride;
-    if (fp8) {  // the expanded copies are contiguous (rows, heads, d)
-        kp.q_row_stride = ws_q_row; kp.q_head_stride = p->d; kp.q_batch_stride = ws_q_row * p->seqlen_q;
-        kp.k_row_stride = kp.v_row_stride = ws_k_row; kp.k_head_stride = kp.v_head_stride = p->d;
-        kp.k_batch_stride = kp.v_batch_stride = ws_k_row * p->seqlen_k;
+    if (fp8) {
+        if (!native8) {  // the expanded copies are contiguous (rows, heads, d)
+            kp.q_row_stride = ws_q_row; kp.q_head_stride = p->d; kp.q_batch_stride = ws_q_row * p->seqlen_q;
+            kp.k_row_stride = kp.v_row_stride = ws_k_row; kp.k_head_stride = kp.v_head_stride = p->d;
+            kp.k_batch_stride = kp.v_batch_stride = ws_k_row * p->seqlen_k;
+        }
         kp.q_descale = p->q_descale; kp.k_descale = p->k_descale; kp.v_descale = p->v_descale;
         kp.qd_bs = (int32_t)p->q_descale_batch_stride; kp.qd_hs = (int32_t)p->q_descale_head_stride;
         kp.kd_bs = (int32_t)p->k_descale_batch_stride; kp.kd_hs = (int32_t)p->k_descale_head_stride;
@@ -766,6 +793,22 @@ int fa_fwd(const fa_fwd_params *p, void *stream_) {
         kp.scale_log2 = p->softmax_scale * kLog2e;
     }
 
+    if (native8) {  // e4m3 operands straight into the block-scaled MFMA (effective_variant() is 0 here: 256-row workgroups)
+        constexpr int smem = fa::smem_bytes_fp8();
+        static std::atomic<uint64_t> attr_set{0};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const uint64_t bit = uint64_t(1) << (dev & 63);
+        if (!(attr_set.load(std::memory_order_acquire) & bit)) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(fa::fwd_kernel_fp8), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) {
+                (void)hipGetLastError();
+                return FA_ERR_LAUNCH;
+            }
+            attr_set.fetch_or(bit, std::memory_order_release);
+        }
+        hipLaunchKernelGGL(fa::fwd_kernel_fp8, dim3(kp.grid), dim3(256), smem, stream, kp);
+        return hipGetLastError() == hipSuccess ? FA_OK : FA_ERR_LAUNCH;
+    }
     const bool bf16 = p->dtype == FA_DTYPE_BF16 || fp8;  // fp8: out is bf16
     const int st_main = bf16 ? dispatch_hdim<__bf16>(kp, softcap, variant, stream)
                              : dispatch_hdim<_Float16>(kp, softcap, variant, stream);

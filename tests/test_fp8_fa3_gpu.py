@@ -67,17 +67,47 @@ def test_fp8_output(sq, sk, d, mha_type, causal):
     _check(out, out_ref, out_pt)
 
 
-def test_fp8_without_descales_equals_bf16_path():
-    """No descales: the fp8 path must equal the bf16 kernel run on the expanded values, bit for bit (the expansion
-    e4m3 -> bf16 is exact and everything downstream is the same kernel)."""
+def test_fp8_expansion_path_equals_bf16_path():
+    """The fp8 shapes the native kernel does not take (here: forced by an explicit kernel variant) run on the exact
+    e4m3 -> bf16 expansion in front of the 16-bit kernel: without descales that equals the bf16 kernel run on the expanded
+    values, bit for bit."""
+    from flash_attention_annotated_amd import _lib
     fa3 = _fa3()
+    lib = _lib.load()
     torch.manual_seed(1)
     q = torch.randn(2, 300, 4, 128, dtype=torch.bfloat16).to(FP8)
     k = torch.randn(2, 333, 2, 128, dtype=torch.bfloat16).to(FP8)
     v = torch.randn(2, 333, 2, 128, dtype=torch.bfloat16).to(FP8)
-    o8 = fa3.flash_attn_func(q.to(DEV), k.to(DEV), v.to(DEV), causal=True)
-    o16 = fa3.flash_attn_func(q.to(torch.bfloat16).to(DEV), k.to(torch.bfloat16).to(DEV), v.to(torch.bfloat16).to(DEV), causal=True)
+    try:
+        lib.fa_set_default_variant(3)
+        o8 = fa3.flash_attn_func(q.to(DEV), k.to(DEV), v.to(DEV), causal=True)
+        o16 = fa3.flash_attn_func(q.to(torch.bfloat16).to(DEV), k.to(torch.bfloat16).to(DEV), v.to(torch.bfloat16).to(DEV), causal=True)
+    finally:
+        lib.fa_set_default_variant(0)
     assert torch.equal(o8, o16)
+
+
+def test_fp8_native_close_to_expansion_path():
+    """Native e4m3 MFMA path (P rounded to e4m3 with the 2^OFF offset) against the exact-expansion path of the same inputs:
+    the difference is the e4m3 rounding of P only -- well inside the FA3 tolerance (the reference's own yardstick rounds P
+    through e4m3 WITHOUT an offset, hopper/test_flash_attn.py:180) -- and the LSE is the same up to fp32 rounding."""
+    from flash_attention_annotated_amd import _lib
+    fa3 = _fa3()
+    lib = _lib.load()
+    torch.manual_seed(5)
+    for sq, sk, causal in ((512, 512, False), (700, 1500, True), (2048, 2048, True)):
+        q = torch.randn(2, sq, 4, 128, dtype=torch.bfloat16).to(FP8).to(DEV)
+        k = torch.randn(2, sk, 2, 128, dtype=torch.bfloat16).to(FP8).to(DEV)
+        v = torch.randn(2, sk, 2, 128, dtype=torch.bfloat16).to(FP8).to(DEV)
+        on, ln = fa3.flash_attn_func(q, k, v, causal=causal, return_attn_probs=True)
+        try:
+            lib.fa_set_default_variant(3)
+            oe, le = fa3.flash_attn_func(q, k, v, causal=causal, return_attn_probs=True)
+        finally:
+            lib.fa_set_default_variant(0)
+        assert (ln - le).abs().max().item() < 1e-3
+        d = (on.float() - oe.float()).abs()
+        assert d.max().item() < 0.15 and d.mean().item() < 5e-3  # (e4m3 keeps 3 mantissa bits of each probability)
 
 
 def test_fp8_varlen_with_seqused():

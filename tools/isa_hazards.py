@@ -9,6 +9,7 @@ import re
 import sys
 
 MFMA_RESULT_STATES = 11  # 8-pass XDL result -> any non-MFMA reader (what hipcc pads for its own MFMAs: s_nop 10)
+MFMA_RESULT_STATES_16PASS = 19  # the 64-cycle forms (v_mfma*_32x32x64_f8f6f4): 16 passes
 REQUIRED = 2  # the guide's figure; the scan is run with a margin (see tests/test_isa_hazards.py)
 
 
@@ -71,10 +72,11 @@ def scan(path, required=REQUIRED):
             for t in toks:
                 touched |= regs(t)
             for dist, dst, text, ln in mfma_out:
-                if dist < MFMA_RESULT_STATES and (dst & touched):
+                if dist < (MFMA_RESULT_STATES_16PASS if '32x32x64' in text else MFMA_RESULT_STATES) and (dst & touched):
                     if op.startswith('v_mfma'):
                         # allowed: accumulate chain (same tuple as SrcC and vDst); anything else is flagged
-                        if regs(toks[0]) == dst and regs(toks[-1].split()[0]) == dst and not (
+                        srcc = toks[3].split()[0] if op.startswith('v_mfma_scale') else toks[-1].split()[0]
+                        if regs(toks[0]) == dst and regs(srcc) == dst and not (
                                 (regs(toks[1]) | regs(toks[2])) & dst):
                             continue
                     violations.append((kernel, ln, text, lineno, l, dist))
@@ -96,7 +98,7 @@ def scan(path, required=REQUIRED):
             elif op in ('s_waitcnt', 's_barrier') or op.startswith(';'):
                 states = 0  # may retire without spending an issue cycle: do not count on it
         # age the windows
-        mfma_out = [(d + states, dst, t, ln) for d, dst, t, ln in mfma_out if d + states < MFMA_RESULT_STATES + 1]
+        mfma_out = [(d + states, dst, t, ln) for d, dst, t, ln in mfma_out if d + states < MFMA_RESULT_STATES_16PASS + 1]
         if op.startswith('v_mfma'):
             mfma_out.append((0, regs(l.split(None, 1)[1].split(',')[0]), l, lineno))
         window = [(d + states, dst, t, ln) for d, dst, t, ln in window if d + states < required + 1]
