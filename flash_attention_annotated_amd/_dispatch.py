@@ -27,7 +27,7 @@ def aligned(t):
 def launch(q, k, v, out, lse, *, varlen, batch, max_seqlen_q, max_seqlen_k, softmax_scale, causal, window_left,
            window_right, softcap, cu_seqlens_q=None, cu_seqlens_k=None, seqused_q=None, seqused_k=None,
            q_descale=None, k_descale=None, v_descale=None, alibi_slopes=None, kv_batch_idx=None, block_table=None, num_splits=1, leftpad_k=None,
-           p_dropout=0.0, rng_state=None, s_dmask=None):
+           p_dropout=0.0, rng_state=None, s_dmask=None, fa3_window=False):
     """q/k/v/out: dense (b, s, h, d) or packed (total, h, d) tensors on one GPU, last stride 1, aligned()."""
     lib = _lib.load()
     prm = _lib.new_params()
@@ -72,6 +72,7 @@ def launch(q, k, v, out, lse, *, varlen, batch, max_seqlen_q, max_seqlen_k, soft
     prm.leftpad_k = ptr(leftpad_k)
     prm.p_dropout = float(p_dropout)
     prm.rng_state, prm.s_dmask = ptr(rng_state), ptr(s_dmask)
+    prm.flags = _lib.FA_FLAG_FA3_WINDOW if fa3_window else 0
     prm.num_splits = int(num_splits)  # 1 = off (prefill entry points), 0 = library heuristic (decode), N = forced
     if block_table is not None:
         prm.block_table = ptr(block_table)
@@ -97,7 +98,7 @@ def launch(q, k, v, out, lse, *, varlen, batch, max_seqlen_q, max_seqlen_k, soft
 
 def launch_bwd(dout, q, k, v, out, lse, dq, dk, dv, softmax_d, *, varlen, batch, max_seqlen_q, max_seqlen_k,
                softmax_scale, causal, window_left, window_right, softcap, cu_seqlens_q=None, cu_seqlens_k=None,
-               alibi_slopes=None, deterministic=False, p_dropout=0.0, rng_state=None):
+               alibi_slopes=None, deterministic=False, p_dropout=0.0, rng_state=None, fa3_window=False):
     """All tensors dense (b, s, h, d) or packed (total, h, d), last stride 1, aligned(); softmax_d fp32
     (b, h, row_len) / (h, row_len).  Enqueues fa_bwd (include/fa_bwd.h) on torch's current stream."""
     lib = _lib.load()
@@ -131,6 +132,7 @@ def launch_bwd(dout, q, k, v, out, lse, dq, dk, dv, softmax_d, *, varlen, batch,
     if alibi_slopes is not None:
         prm.alibi_slopes = ptr(alibi_slopes)
         prm.alibi_slopes_batch_stride = alibi_slopes.stride(0) if alibi_slopes.dim() == 2 else 0
+    prm.flags = _lib.FA_FLAG_FA3_WINDOW if fa3_window else 0
     prm.deterministic = int(bool(deterministic))
     prm.p_dropout = float(p_dropout)
     prm.rng_state = ptr(rng_state)

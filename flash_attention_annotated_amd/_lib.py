@@ -14,7 +14,8 @@ LIB_PATH = os.path.join(_HERE, LIB_NAME)
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
-FA_ABI_VERSION = 9
+FA_ABI_VERSION = 10
+FA_FLAG_FA3_WINDOW = 1
 FA_DTYPE_FP16, FA_DTYPE_BF16, FA_DTYPE_FP8_E4M3 = 0, 1, 2
 
 # every symbol include/fa_fwd.h declares (tests check the .so exports all of them)
@@ -102,7 +103,7 @@ class FaFwdParams(ctypes.Structure):
         ("num_splits", ctypes.c_int32),
         ("leftpad_k", ctypes.c_void_p),
         ("p_dropout", ctypes.c_float),
-        ("reserved1", ctypes.c_int32),
+        ("flags", ctypes.c_int32),
         ("rng_state", ctypes.c_void_p),
         ("s_dmask", ctypes.c_void_p),
     ]
@@ -165,18 +166,41 @@ class FaBwdParams(ctypes.Structure):
         + [("is_causal", ctypes.c_int32), ("window_size_left", ctypes.c_int32), ("window_size_right", ctypes.c_int32)]
         + [("alibi_slopes", ctypes.c_void_p), ("alibi_slopes_batch_stride", ctypes.c_int64)]
         + [("deterministic", ctypes.c_int32), ("p_dropout", ctypes.c_float), ("rng_state", ctypes.c_void_p)]
+        + [("flags", ctypes.c_int32), ("reserved2", ctypes.c_int32)]
     )
+
+
+HASH_PATH = os.path.join(_HERE, "libfa_fwd_gfx950.srchash")
+
+
+def _deps():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))) + [
+        os.path.join(INCLUDE, "fa_fwd.h"), os.path.join(INCLUDE, "fa_bwd.h")]
+
+
+def source_hash():
+    """sha256 over the sources the library is built from (what build() records next to the library)."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in _deps():
+        h.update(os.path.basename(path).encode())
+        h.update(open(path, "rb").read())
+    return h.hexdigest()
+
+
+def is_stale():
+    """True when the built library is missing or was not built from the sources in the tree (content hash, not mtimes:
+    the tree is copied to the GPU box)."""
+    if not os.path.exists(LIB_PATH) or not os.path.exists(HASH_PATH):
+        return True
+    return open(HASH_PATH).read().strip() != source_hash()
 
 
 def build(force=False, verbose=False):
     """Compile csrc/ for gfx950 into the in-tree shared library (hipcc cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, "fa_fwd_api.hip"), os.path.join(CSRC, "fa_bwd_api.hip")]
-    deps = srcs + [os.path.join(CSRC, "fa_fwd_kernel.h"), os.path.join(CSRC, "fa_fwd_kernel_w64.h"), os.path.join(CSRC, "fa_fwd_loop_gen.h"), os.path.join(CSRC, "fa_fwd_kernel_fp8.h"), os.path.join(CSRC, "fa_fwd_loop_fp8_gen.h"),
-                   os.path.join(CSRC, "fa_bwd_kernel.h"), os.path.join(INCLUDE, "fa_fwd.h"),
-                   os.path.join(INCLUDE, "fa_bwd.h")]
-    if not force and os.path.exists(LIB_PATH):
-        if os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps):
-            return LIB_PATH
+    if not force and not is_stale():
+        return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
@@ -185,6 +209,8 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
+    with open(HASH_PATH, "w") as f:
+        f.write(source_hash() + "\n")
     return LIB_PATH
 
 

@@ -98,7 +98,7 @@ int run_bwd(fa::BParams bp, int rows_q_max, int rows_k_max, hipStream_t stream) 
 
 template <typename T>
 int dispatch_bwd(const fa::BParams &bp, bool softcap, int sq, int sk, hipStream_t stream) {
-    const bool drop = bp.drop_thr < 255;  // (never together with softcap: fa_bwd_validate)
+    const bool drop = bp.rp_dropout != 1.f;  // p > 0 (never together with softcap: fa_bwd_validate)
     switch (head_dim_tile_b(bp.d)) {
         case 64:
             if (drop) return run_bwd<T, 64, false, true>(bp, sq, sk, stream);
@@ -189,10 +189,13 @@ int fa_bwd(const fa_bwd_params *p, void *stream_) {
 
     // window normalisation exactly as the forward (fa_fwd_api.hip; csrc/flash_attn/flash_api.cpp:790,836-837)
     int wl = p->window_size_left, wr = p->window_size_right;
-    if (wl >= p->seqlen_k) wl = -1;
-    if (wr >= p->seqlen_k) wr = -1;
     if (p->is_causal) wr = 0;
-    if (wl >= 0 && wr < 0) wr = p->seqlen_k;
+    if (!(p->flags & FA_FLAG_FA3_WINDOW)) {  // (FA3 rule: a negative side is unbounded, include/fa_fwd.h)
+        if (wl >= p->seqlen_k) wl = -1;
+        if (wr >= p->seqlen_k) wr = -1;
+        if (p->is_causal) wr = 0;
+        if (wl >= 0 && wr < 0) wr = p->seqlen_k;
+    }
     bp.window_left = wl;
     bp.window_right = wr;
 
@@ -208,7 +211,7 @@ int fa_bwd(const fa_bwd_params *p, void *stream_) {
     bp.out_scale = p->softmax_scale;
     bp.alibi = p->alibi_slopes;
     bp.alibi_bs = (int32_t)p->alibi_slopes_batch_stride;
-    bp.drop_thr = p->p_dropout > 0.f ? std::min(254, (int)std::floor(255.0 * (1.0 - (double)p->p_dropout))) : 255;  // as fa_fwd
+    bp.drop_thr = p->p_dropout > 0.f ? (int)std::floor(255.0 * (1.0 - (double)p->p_dropout)) : 255;  // as fa_fwd
     bp.rp_dropout = p->p_dropout > 0.f ? 1.f / (1.f - p->p_dropout) : 1.f;
     bp.rng_state = p->rng_state;
 

@@ -210,7 +210,7 @@ bool fp8_native(const fa_fwd_params *p) {
     const int variant = p->kernel_variant ? p->kernel_variant : g_default_variant.load();
     if (variant != 0) return false;
     if (p->softcap > 0.f || p->alibi_slopes || p->block_table || p->kv_batch_idx || p->leftpad_k || p->p_dropout > 0.f) return false;
-    if (p->window_size_left >= 0 && p->window_size_left < p->seqlen_k) return false;
+    if (p->window_size_left >= 0 && ((p->flags & FA_FLAG_FA3_WINDOW) || p->window_size_left < p->seqlen_k)) return false;
     const int64_t strides[] = {p->q_row_stride, p->q_head_stride, p->k_row_stride, p->k_head_stride, p->v_row_stride,
                                p->v_head_stride, p->cu_seqlens_q ? 0 : p->q_batch_stride, p->cu_seqlens_q ? 0 : p->k_batch_stride,
                                p->cu_seqlens_q ? 0 : p->v_batch_stride};
@@ -434,7 +434,7 @@ int dispatch_variant(const fa::KParams &kp, bool softcap, int variant, hipStream
     // variant 1  : 8 waves x 32 rows (BLOCK_M 256), two waves per SIMD (fa_fwd_kernel.h)
     // variant 2  : 4 waves x 32 rows (BLOCK_M 128)
     // D = 256 does not fit the w64 register budget (O alone would be 256 registers): 4 waves x 32 rows.
-    if (kp.drop_thr < 255) {  // dropout: its own instantiation of the compiler-scheduled shape (never with softcap)
+    if (kp.rp_dropout != 1.f) {  // dropout (p > 0, also when its 8-bit threshold keeps everything): its own instantiation of the compiler-scheduled shape (never with softcap)
         if constexpr (D == 256) return launch<T, D, 4, false, true>(kp, stream);
         else return launch<T, D, 8, false, true>(kp, stream);
     }
@@ -741,6 +741,17 @@ int fa_fwd(const fa_fwd_params *p, void *stream_) {
     const int64_t grid = 8 * ((units + 7) / 8) * kp.unit_tiles;
     if (grid > 0x7fffffff) return FA_ERR_BAD_SHAPE;
     kp.grid = (int32_t)grid;
+    {   // compute units of the current device (cached per device ordinal)
+        static std::atomic<int> cus[64];
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        int n = cus[dev & 63].load(std::memory_order_relaxed);
+        if (n == 0) {
+            if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+            cus[dev & 63].store(n, std::memory_order_relaxed);
+        }
+        kp.num_cus = n;
+    }
     // split-KV: `splits` copies of the grid; partial results go to the workspace and are merged below
     const SplitPlan sp = nothing ? SplitPlan{1, 0, 0, 0} : split_plan(p, variant);
     kp.num_splits = sp.splits;
@@ -756,14 +767,20 @@ int fa_fwd(const fa_fwd_params *p, void *stream_) {
 
     // window normalisation: csrc/flash_attn/flash_api.cpp:396-402
     int wl = p->window_size_left, wr = p->window_size_right;
-    if (wl >= p->seqlen_k) wl = -1;
-    if (wr >= p->seqlen_k) wr = -1;
     if (p->is_causal) wr = 0;
-    // set_params_fprop csrc/flash_attn/flash_api.cpp:141-142: a one-sided window gets seqlen_k on the other side.
-    // For a left-only window that is NOT the same as unbounded when seqlen_q > seqlen_k (the bottom-right aligned
-    // diagonal starts left of key 0), so it is mirrored.  The symmetric rule (right-only -> left = seqlen_k) never
-    // masks anything (row + sk - sq - seqlen_k < 0 for every row) and is left as "unbounded".
-    if (wl >= 0 && wr < 0) wr = p->seqlen_k;
+    if (p->flags & FA_FLAG_FA3_WINDOW) {
+        // FA3 rule (hopper/flash_api.cpp:152-153, 589-590): a missing side becomes seqlen_k - 1 / seqlen_q - 1, which never
+        // masks anything = unbounded here; sides are taken as given otherwise
+    } else {
+        if (wl >= p->seqlen_k) wl = -1;
+        if (wr >= p->seqlen_k) wr = -1;
+        if (p->is_causal) wr = 0;
+        // set_params_fprop csrc/flash_attn/flash_api.cpp:141-142: a one-sided window gets seqlen_k on the other side.
+        // For a left-only window that is NOT the same as unbounded when seqlen_q > seqlen_k (the bottom-right aligned
+        // diagonal starts left of key 0), so it is mirrored.  The symmetric rule (right-only -> left = seqlen_k) never
+        // masks anything (row + sk - sq - seqlen_k < 0 for every row) and is left as "unbounded".
+        if (wl >= 0 && wr < 0) wr = p->seqlen_k;
+    }
     kp.window_left = wl;
     kp.window_right = wr;
 
@@ -771,8 +788,8 @@ int fa_fwd(const fa_fwd_params *p, void *stream_) {
     kp.alibi_bs = (int32_t)p->alibi_slopes_batch_stride;
     kp.leftpad_k = p->leftpad_k;
     // dropout: keep iff randval <= floor(255 (1 - p)); 255 = everything kept = the branch is off
+    // (the reference's quantisation: p < 1/255 gives threshold 255 = nothing dropped, still scaled by 1 / (1 - p))
     kp.drop_thr = p->p_dropout > 0.f ? (int32_t)std::floor(255.0 * (1.0 - (double)p->p_dropout)) : 255;
-    if (p->p_dropout > 0.f && kp.drop_thr >= 255) kp.drop_thr = 254;  // (p < 1/255 would otherwise switch it off)
     kp.rp_dropout = p->p_dropout > 0.f ? 1.f / (1.f - p->p_dropout) : 1.f;
     kp.rng_state = p->rng_state;
     kp.s_dmask = p->s_dmask;

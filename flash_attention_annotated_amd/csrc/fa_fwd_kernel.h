@@ -54,6 +54,7 @@ struct KParams {
     int32_t num_tiles;     // num_m_blocks * h * b  (work list length)
     int32_t unit_tiles;    // tiles per scheduling unit (see decode_tile)
     int32_t grid;          // workgroups launched = 8 * ceil(units / 8) * unit_tiles
+    int32_t num_cus;       // compute units of the device (one 256-thread workgroup of the pipelined kernels per CU)
     int32_t window_left, window_right;  // <0 unbounded; causal => right = 0
     float scale;           // softmax_scale (softcap: the softcap value)
     float scale_log2;      // scale * log2(e)

@@ -222,6 +222,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_fp8(const KParams p) {
                 for (int e = 0; e < 4; ++e) { kf[e] = k0[e]; kf[4 + e] = k1[e]; }
                 if (st == 0) { MfmaF8::s_first(sa_[beta], kf, qa[0], one); MfmaF8::s_first(sb_[beta], kf, qb[0], one); }
                 else { MfmaF8::s_acc(sa_[beta], kf, qa[1], one); MfmaF8::s_acc(sb_[beta], kf, qb[1], one); }
+                __builtin_amdgcn_sched_barrier(0);  // (boundary code: keep hipcc from hoisting every fragment read -> spills)
             }
     };
     auto pv_tile = [&](int vbuf, const u32x8 &pa, const u32x8 &pb) {
@@ -238,6 +239,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_fp8(const KParams p) {
             }
             MfmaF8::o_acc(oa[db], vf, pa, one);
             MfmaF8::o_acc(ob[db], vf, pb, one);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
     auto drain_scores = [&](f32x16 (&s0)[2], f32x16 (&s1)[2]) {
@@ -249,9 +251,11 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_fp8(const KParams p) {
     auto rescale = [&](f32x16 (&o)[4], float alpha) {
         asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 7" : "+a"(o[0]), "+a"(o[1]), "+a"(o[2]), "+a"(o[3]));
 #pragma unroll
-        for (int db = 0; db < 4; ++db)
+        for (int db = 0; db < 4; ++db) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) o[db][i] *= alpha;
+            __builtin_amdgcn_sched_barrier(0);
+        }
         asm volatile("s_nop 15\n\ts_nop 7" : "+a"(o[0]), "+a"(o[1]), "+a"(o[2]), "+a"(o[3]));
     };
     // mask of the scores of tile n (keys 64 n + 32 hh + 16 beta + i in register i of block beta); boundary tiles only
@@ -309,6 +313,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_fp8(const KParams p) {
                 cvt_pk_fp8_lo(w, t[0], t[1]);
                 cvt_pk_fp8_hi(w, t[2], t[3]);
                 pf[4 * beta + g] = w;
+                __builtin_amdgcn_sched_barrier(0);
             }
         l_run = l_run * alpha + (ps0 + ps1);
     };
@@ -386,7 +391,13 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_fp8(const KParams p) {
 
     int i = 0;
     while (i < n_max) {
-        int count = fast_last - i;  // tiles i .. fast_last-1 (each computes the unmasked scores of its successor)
+        // tiles i .. fast_last-1 (each computes the unmasked scores of its successor), plus -- when the wave's LAST tile is
+        // itself unmasked -- that tile as a `phantom` call of its own: the block then forms S(tend) / P_A(tend) from
+        // whatever K tile follows (real keys behind a causal diagonal, or the zeros that rows past the end read as) with the
+        // look-ahead guards off (threshold +inf); nothing of that is used, and l_a is restored from l_a_saved.
+        const bool last_unmasked = fast_last == tend - 1 && tend > 0;
+        const bool phantom = last_unmasked && i == tend - 1;
+        int count = phantom ? 1 : fast_last - i;
         if (count >= 1 && !moved_a && (int64_t)sk * k_rs < (1ll << 31) && (int64_t)sk * v_rs < (1ll << 31) &&
             !__any(m_a == -INFINITY || m_b == -INFINITY)) {
             {   // S_B(i) must be safe to exponentiate with the stale m_b (inside the block the look-ahead guarantees it)
@@ -400,11 +411,12 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_fp8(const KParams p) {
             }
             int done = 0;
             uint64_t pend = 0, tripb = 0;
-            float ala = 1.f;
+            float ala = 1.f, l_a_saved = l_a;
             f32x16 sby[2];
             u32x8 pay;
-            FastLoopFp8::run(oa, ob, qa, qb, sa, sbx, sby, pax, pay, l_a, l_b, m_a, ala, m_a * csc - OFF, m_b * csc - OFF, m_b,
-                             (uint32_t)kbase, (uint32_t)vbase, koff, voff, csc, THR / csc, OFF, kdesc, vdesc,
+            FastLoopFp8::run(oa, ob, qa, qb, sa, sbx, sby, pax, pay, l_a, l_b, m_a, ala, l_a_saved, m_a * csc - OFF,
+                             m_b * csc - OFF, m_b, (uint32_t)kbase, (uint32_t)vbase, koff, voff, csc,
+                             phantom ? INFINITY : THR / csc, OFF, kdesc, vdesc,
                              (uint32_t)((i + 3) * BLOCK_N * k_rs), (uint32_t)((i + 2) * BLOCK_N * v_rs),
                              (uint32_t)(BLOCK_N * k_rs), (uint32_t)(BLOCK_N * v_rs), lds0, lds_wave, i % 3, count, done,
                              pend, tripb);
@@ -413,6 +425,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_fp8(const KParams p) {
                 sbx[0] = sby[0]; sbx[1] = sby[1];
                 pax = pay;
             }
+            if (phantom) l_a = l_a_saved;
             if (pend != 0) rescale(oa, ala);
             (void)tripb;  // q-block B's new max is taken at the top of the next iteration (or by the generic tile)
             continue;

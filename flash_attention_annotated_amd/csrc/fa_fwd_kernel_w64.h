@@ -979,7 +979,12 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
         bool tripped = false;
         if constexpr (D == 128 && !SOFTCAP && !(FA_ABLATE & 32)) {
             const int n_cur = n_min + (j >> 1);
-            int count = (fast_last - j) >> 1;  // tiles jt = j, j + 2, .. with jt + 2 <= fast_last
+            // tiles jt = j, j + 2, .. with jt + 2 <= fast_last -- plus the wave's LAST tile when its own half-steps need no mask
+            // (`phantom`): the block then also forms S(jend) / P_A(jend) from whatever K tile follows (real keys behind a causal
+            // diagonal or the zeros that rows past the end of the sequence read as); nothing of that is used, and the
+            // one thing it touches, l_a, is restored from l_a_saved below.
+            const bool phantom = fast_last == jend - 1 && (jend & 1) == 0 && jend - j >= 2 && !(FA_ABLATE & 64);
+            int count = phantom ? (jend - j) >> 1 : (fast_last - j) >> 1;
             // (the descriptors address bytes with 32 bits: longer sequences stay on the C++ form)
             if (count >= 2 && (int64_t)sk * k_rs64 < (1ll << 30) && (int64_t)sk * v_rs64 < (1ll << 30)) {
                 auto make_desc = [&](const T *base, int64_t rs64) {
@@ -1020,6 +1025,10 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
                 j += done;
                 in_flight = 2 * LD_PER_THREAD;
                 redo_a = redo != 0;
+                if (phantom && j == jend) {
+                    l_a = l_a_saved;
+                    redo_a = false;
+                }
                 if (count != 0) {  // a guard tripped: the next half-step is the generic path's
                     tripped = true;
                     if (done & 1) to_canonical_after_odd();
@@ -1110,13 +1119,13 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     tile_barrier<0>();  // every wave's LDS-DMA (incl. look-ahead tiles past the end) has landed: the ring can be reused
     FA_T(5);
     // ---- L2 prefetch for the workgroup that takes this CU next.  Workgroups are dispatched in id order and (apart from
-    // causal imbalance) take equally long, so the successor is id + (number of CUs); it lives on the same XCD (same id mod
+    // causal imbalance) take equally long, so the successor is id + p.num_cus (read from the device by the host); it lives on the same XCD (same id mod
     // 8), i.e. behind the same L2.  Its Q rows are a cold, badly coalesced gather (~4 us: tools/wg_phases.py); touching one
     // dword of each of their cache lines here, with the whole epilogue (~3 us) in front of the end of this workgroup, turns
     // that into L2 hits.  The data lands in a 1 KiB dump area of LDS; dense batches only (no cu_seqlens lookups here).
 #ifndef FA_CYCLES
     if (!p.cu_seqlens_q && !p.seqused_q && p.num_splits <= 1 && p.q_row_stride < (1 << 20)) {
-        const int wg2 = blockIdx.x + 256;
+        const int wg2 = blockIdx.x + p.num_cus;
         const int slot2 = wg2 >> 3;
         const int tile2 = ((slot2 / p.unit_tiles) * 8 + (wg2 & 7)) * p.unit_tiles + slot2 % p.unit_tiles;  // decode_tile()
         if (wg2 < p.grid && tile2 < p.num_tiles) {

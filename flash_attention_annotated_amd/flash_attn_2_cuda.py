@@ -13,7 +13,9 @@ checks, output allocation, params — and enqueue the gfx950 kernel through the 
 `fwd_kvcache` covers the decode path (mha_fwd_kvcache :1202-1476): in-place append, rotary, cache_batch_idx, paged
 and left-padded caches, split-KV.  Dropout / return_softmax are rejected by message.
 """
+import contextlib
 import math
+import threading
 from typing import List, Optional
 
 import torch
@@ -22,6 +24,20 @@ from . import _dispatch, _lib
 from ._dispatch import aligned as _aligned
 
 __all__ = ["fwd", "varlen_fwd", "bwd", "varlen_bwd", "fwd_kvcache"]
+
+
+# The FA3 operator surface (flash_attn_3_ops._bwd) runs its backward through bwd / varlen_bwd below with ITS window rule (a
+# missing side is unbounded, include/fa_fwd.h FA_FLAG_FA3_WINDOW); the reference signatures have no room for that switch.
+_window_rule = threading.local()
+
+
+@contextlib.contextmanager
+def fa3_window_rule():
+    _window_rule.fa3 = True
+    try:
+        yield
+    finally:
+        _window_rule.fa3 = False
 
 
 def _check(cond, msg):
@@ -157,7 +173,10 @@ def fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out_: Optional[torch.
                              max_seqlen_k=seqlen_k, softmax_scale=softmax_scale, causal=is_causal,
                              window_left=window_size_left, window_right=window_size_right, softcap=softcap,
                              alibi_slopes=alibi, p_dropout=p_dropout, rng_state=rng_state if p_dropout > 0 else None,
-                             s_dmask=p if return_softmax else None)
+                             s_dmask=p if return_softmax else None,
+                             # the split heuristic runs whenever there is no dropout, as in mha_fwd (flash_api.cpp:453-456);
+                             # it only splits problems whose tiles leave most CUs idle
+                             num_splits=0 if p_dropout == 0 else 1)
             if oc is not out:
                 out.copy_(oc)
         elif seqlen_q > 0:
@@ -334,7 +353,7 @@ def bwd(dout: torch.Tensor, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, o
                                  max_seqlen_k=seqlen_k, softmax_scale=softmax_scale, causal=is_causal,
                                  window_left=window_size_left, window_right=window_size_right, softcap=softcap,
                                  alibi_slopes=alibi, deterministic=deterministic, p_dropout=p_dropout,
-                                 rng_state=rng_state if p_dropout > 0 else None)
+                                 rng_state=rng_state if p_dropout > 0 else None, fa3_window=getattr(_window_rule, "fa3", False))
             for dst, src in zip((dq, dk, dv), outs):
                 if dst is not src:
                     dst.copy_(src)
@@ -412,7 +431,7 @@ def varlen_bwd(dout: torch.Tensor, q: torch.Tensor, k: torch.Tensor, v: torch.Te
                                  causal=is_causal, window_left=window_size_left, window_right=window_size_right,
                                  softcap=softcap, cu_seqlens_q=cu_seqlens_q, cu_seqlens_k=cu_seqlens_k,
                                  alibi_slopes=alibi, deterministic=deterministic, p_dropout=p_dropout,
-                                 rng_state=rng_state if p_dropout > 0 else None)
+                                 rng_state=rng_state if p_dropout > 0 else None, fa3_window=getattr(_window_rule, "fa3", False))
             for dst, src in zip((dq, dk, dv), outs):
                 if dst is not src:
                     dst.copy_(src)

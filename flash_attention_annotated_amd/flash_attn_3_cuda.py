@@ -59,6 +59,19 @@ def fwd(q, k, v, k_new, v_new, qv, out, cu_seqlens_q, cu_seqlens_k, cu_seqlens_k
                                                int(window_size_left), int(window_size_right), float(softcap),
                                                bool(is_rotary_interleaved), int(num_splits), 1)
         return o, lse, None, None
+    if (cu_seqlens_q is None and cu_seqlens_k is None and seqused_q is None and seqused_k is not None and not is_fp8
+            and q.dim() == 4 and q.shape[1] <= 128 and window_size_left < 0 and (window_size_right < 0 or is_causal)
+            and out is None):
+        # plain decode over a cache (flash_attn_with_kvcache(q, k_cache, v_cache, cache_seqlens=...)): the same routine as
+        # the append / paged calls, which brings the split-KV heuristic (num_splits = 0) and the (b, 1, h) -> (b, ngroups, h_k)
+        # GQA swap (hopper/flash_api.cpp:935-1060 runs them for every call with seqused_k)
+        if softmax_scale is None:
+            softmax_scale = q.shape[-1] ** (-0.5)
+        from . import flash_attn_2_cuda
+        o, lse = flash_attn_2_cuda._fwd_kvcache_impl(q, k, v, None, None, seqused_k, None, None, None, None, None, None, None,
+                                               softmax_scale, bool(is_causal), -1, -1, float(softcap), False,
+                                               int(num_splits), 1)
+        return o, lse, None, None
     varlen_q = cu_seqlens_q is not None
     varlen_k = cu_seqlens_k is not None
     _check(varlen_q == varlen_k, "This flash attention build needs cu_seqlens_q and cu_seqlens_k together.")
@@ -113,7 +126,8 @@ def fwd(q, k, v, k_new, v_new, qv, out, cu_seqlens_q, cu_seqlens_k, cu_seqlens_k
                              max_seqlen_k=seqlen_k, softmax_scale=softmax_scale, causal=is_causal,
                              window_left=window_size_left, window_right=window_size_right, softcap=softcap,
                              cu_seqlens_q=cu_seqlens_q, cu_seqlens_k=cu_seqlens_k, seqused_q=seqused_q,
-                             seqused_k=seqused_k, q_descale=q_descale, k_descale=k_descale, v_descale=v_descale)
+                             seqused_k=seqused_k, q_descale=q_descale, k_descale=k_descale, v_descale=v_descale,
+                             fa3_window=True)  # a missing window side is unbounded (hopper/flash_api.cpp:152-153)
             if oc is not out:
                 out.copy_(oc)
         elif total_q > 0:

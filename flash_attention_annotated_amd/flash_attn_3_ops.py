@@ -62,15 +62,26 @@ def _bwd(dout, q, k, v, out, softmax_lse, dq=None, dk=None, dv=None, cu_seqlens_
         raise RuntimeError("This flash attention build does not support seqused_q / seqused_k in the backward.")
     if softmax_scale is None:
         softmax_scale = q.shape[-1] ** (-0.5)
-    if cu_seqlens_q is not None:
-        dq, dk, dv, sd = flash_attn_2_cuda.varlen_bwd(dout, q, k, v, out, softmax_lse, dq, dk, dv, cu_seqlens_q, cu_seqlens_k,
-                                                     None, int(max_seqlen_q), int(max_seqlen_k), 0.0, softmax_scale, False,
-                                                     is_causal, window_size_left, window_size_right, softcap, deterministic,
-                                                     None, None)
-    else:
-        dq, dk, dv, sd = flash_attn_2_cuda.bwd(dout, q, k, v, out, softmax_lse, dq, dk, dv, None, 0.0, softmax_scale,
-                                               is_causal, window_size_left, window_size_right, softcap, deterministic,
-                                               None, None)
+    # window normalisation of the FA3 entry points (hopper/flash_api.cpp:1360-1361, as :796-797 of the forward): a side that
+    # cannot mask anything becomes -1 = unbounded and stays unbounded (FA_FLAG_FA3_WINDOW)
+    sq_max = int(max_seqlen_q) if cu_seqlens_q is not None else q.shape[1]
+    sk_max = int(max_seqlen_k) if cu_seqlens_q is not None else k.shape[1]
+    if window_size_left >= sk_max - 1:
+        window_size_left = -1
+    if window_size_right >= sq_max - 1:
+        window_size_right = -1
+    if is_causal:
+        window_size_right = 0
+    with flash_attn_2_cuda.fa3_window_rule():
+        if cu_seqlens_q is not None:
+            dq, dk, dv, sd = flash_attn_2_cuda.varlen_bwd(dout, q, k, v, out, softmax_lse, dq, dk, dv, cu_seqlens_q, cu_seqlens_k,
+                                                         None, int(max_seqlen_q), int(max_seqlen_k), 0.0, softmax_scale, False,
+                                                         is_causal, window_size_left, window_size_right, softcap,
+                                                         deterministic, None, None)
+        else:
+            dq, dk, dv, sd = flash_attn_2_cuda.bwd(dout, q, k, v, out, softmax_lse, dq, dk, dv, None, 0.0, softmax_scale,
+                                                   is_causal, window_size_left, window_size_right, softcap, deterministic,
+                                                   None, None)
     e = torch.empty(0, dtype=torch.float32, device=q.device)  # softmax_lse_log2, dq_accum, dk_accum, dv_accum: none here
     return dq, dk, dv, sd, e, e.clone(), e.clone(), e.clone()
 

@@ -74,7 +74,7 @@ def _flash_attn_forward_fake(q, k, v, dropout_p, softmax_scale, causal, window_s
     """reference :109-136 (on HIP the fake `p` is the unrounded (b, h, sq, sk), :130-131)"""
     batch_size, seqlen_q, num_heads, _ = q.shape
     seqlen_k = k.shape[1]
-    out = torch.empty_like(q, memory_format=torch.contiguous_format)
+    out = torch.empty_like(q)  # (same strides as the real op: flash_attn_2_cuda.fwd allocates empty_like(q))
     softmax_lse = torch.empty((batch_size, num_heads, seqlen_q), dtype=torch.float32, device=q.device)
     p = torch.empty((0,), dtype=q.dtype, device=q.device)
     if return_softmax:
@@ -161,7 +161,7 @@ def _flash_attn_varlen_forward_fake(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seq
     """reference :196-233"""
     batch_size = cu_seqlens_q.numel() - 1
     total_q, num_heads, _ = q.shape
-    out = torch.empty_like(q, memory_format=torch.contiguous_format)
+    out = torch.empty_like(q)  # (same strides as the real op: flash_attn_2_cuda.fwd allocates empty_like(q))
     softmax_lse = torch.empty((num_heads, total_q), dtype=torch.float32, device=q.device)
     p = torch.empty((0,), dtype=q.dtype, device=q.device)
     if return_softmax:

@@ -74,6 +74,8 @@ typedef struct fa_bwd_params {
     int32_t deterministic; /* accepted; results are always bit-reproducible */
     float p_dropout;       /* as fa_fwd_params; rng_state must be the pair the forward used */
     const uint64_t *rng_state;
+    int32_t flags;         /* FA_FLAG_* as fa_fwd_params (FA_FLAG_FA3_WINDOW) */
+    int32_t reserved2;
 } fa_bwd_params;
 
 /* Validate and enqueue the backward on `stream`.  Returns FA_OK or a negative fa_status; asynchronous. */

@@ -38,7 +38,9 @@
 extern "C" {
 #endif
 
-#define FA_ABI_VERSION 9
+#define FA_ABI_VERSION 10
+
+#define FA_FLAG_FA3_WINDOW 1
 
 /* element types of q/k/v (o has the same type; fp8 inputs produce bf16 o) */
 enum fa_dtype {
@@ -167,7 +169,10 @@ typedef struct fa_fwd_params {
      * dense (b, h, seqlen_q, seqlen_k), varlen (h, total_q, seqlen_k [= max_seqlen_k]).  Dropout runs on the
      * compiler-scheduled kernel shape (no split-KV). */
     float p_dropout;
-    int32_t reserved1;
+    /* FA_FLAG_* bits.  FA_FLAG_FA3_WINDOW: window sides follow the FA3 rule (hopper/flash_api.cpp:152-153, 589-590): a
+     * negative side is UNBOUNDED and stays so; without the flag a one-sided window gets seqlen_k on the other side as
+     * set_params_fprop does (csrc/flash_attn/flash_api.cpp:141-142), which masks rows when seqlen_q > seqlen_k. */
+    int32_t flags;
     const uint64_t *rng_state;
     uint8_t *s_dmask;
 } fa_fwd_params;

@@ -233,3 +233,35 @@ def test_fa3_interface_autograd_matches_fa2_surface():
     assert torch.equal(o3, o2) and torch.equal(dp, want)
     meta = fa3.get_scheduler_metadata(b, 1, 4096, h, hk, d, torch.full((b,), 100, dtype=torch.int32, device=DEV))
     assert meta.dtype == torch.int32
+
+
+@pytest.mark.parametrize("sq,sk,window", [(300, 120, (50, -1)), (300, 120, (-1, 40)), (257, 515, (64, -1))])
+def test_fa3_one_sided_window(sq, sk, window):
+    """FA3 rule for a one-sided sliding window (hopper/flash_api.cpp:152-153, 589-590): the missing side is unbounded -- also
+    when seqlen_q > seqlen_k, where the FA2 rule (the other side becomes seqlen_k) would mask whole rows.  Forward and
+    backward; the oracle gets the equivalent two-sided window."""
+    fa3 = _fa3()
+    torch.manual_seed(4)
+    b, h, hk, d = 2, 4, 2, 64
+    q = torch.randn(b, sq, h, d, dtype=torch.bfloat16)
+    k = torch.randn(b, sk, hk, d, dtype=torch.bfloat16)
+    v = torch.randn(b, sk, hk, d, dtype=torch.bfloat16)
+    g = torch.randn(b, sq, h, d, dtype=torch.bfloat16)
+    qd, kd, vd = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
+    out = fa3.flash_attn_func(qd, kd, vd, window_size=window)
+    grads = torch.autograd.grad(out, (qd, kd, vd), g.to(DEV))
+    big = sq + sk
+    w2 = (window[0] if window[0] >= 0 else big, window[1] if window[1] >= 0 else big)
+
+    def ref(**kw):
+        ql, kl, vl = (t.clone().requires_grad_(True) for t in (q, k, v))
+        o, _ = oracle.attention_ref(ql, kl, vl, window_size=w2, **kw)
+        return o, torch.autograd.grad(o, (ql, kl, vl), g)
+    out_ref, g_ref = ref()
+    out_pt, g_pt = ref(upcast=False, reorder_ops=True)
+    assert torch.isfinite(out.float()).all()
+    err = (out.float().cpu() - out_ref.float()).abs().max().item()
+    assert err <= 2 * (out_pt.float() - out_ref.float()).abs().max().item() + 1e-5, err
+    for name, got, r, pt in zip(("dq", "dk", "dv"), grads, g_ref, g_pt):
+        e = (got.float().cpu() - r.float()).abs().max().item()
+        assert e <= 3 * (pt.float() - r.float()).abs().max().item() + 1e-4, (name, e)

@@ -37,12 +37,12 @@ LD = 2                      # LDS-DMA pieces per wave, tile and matrix
 # ---- register map (arch VGPRs) ----
 SA, SBX, SBY = 0, 32, 64            # 2 blocks x 16 each
 PAX, PAY, PB = 96, 104, 112         # 8 dwords each (32 e4m3 probabilities per lane)
-KF, VF = 224, 240                   # double buffers of 8, in AGPRs (LDS reads and MFMA A operands take them directly)
+KF, VF = 120, 136                   # double buffers of 8
 KA, VA = 168, 172                   # 4 + 8 LDS address registers
 KOFF, VOFF = 180, 182
 MCA, MCB, LA, LB0, MA, MB = 184, 185, 186, 187, 188, 189
 T0, T1, T2, T3, NXA0, NXA1, NXB0, NXB1 = 190, 191, 192, 193, 194, 195, 196, 197
-LB1, ONE, MAT, MBT, ALA, KBASE, VBASE, PSA0, PSA1 = 198, 199, 200, 201, 202, 203, 204, 205, 206
+LB1, ONE, MAT, MBT, ALA, KBASE, VBASE, PSA0, PSA1, LAS = 198, 199, 200, 201, 202, 203, 204, 205, 206, 207
 MFMA = "v_mfma_scale_f32_32x32x64_f8f6f4"
 
 
@@ -67,12 +67,12 @@ class Emitter:
 
     def ds_k(self, dst, st, off, tag):
         for e_ in range(2):
-            self.e(f"ds_read_b128 {a(dst + 4 * e_, 4)}, {v(KA + 2 * st + e_)} offset:{off}")
+            self.e(f"ds_read_b128 {v(dst + 4 * e_, 4)}, {v(KA + 2 * st + e_)} offset:{off}")
             self.lds_q.append(tag)
 
     def ds_v(self, dst, db, off, tag):
         for t in range(4):
-            self.e(f"ds_read_b64_tr_b8 {a(dst + 2 * t, 2)}, {v(VA + 2 * db + (t & 1))} offset:{off + 1024 * t}")
+            self.e(f"ds_read_b64_tr_b8 {v(dst + 2 * t, 2)}, {v(VA + 2 * db + (t & 1))} offset:{off + 1024 * t}")
             self.lds_q.append(tag)
 
     def wait_for(self, tag):
@@ -139,11 +139,11 @@ def gen_tile(E, slot, uid):
         E.wait_for(("k", uid, q))
         c_a = "0" if st == 0 else v(SA + 16 * beta, 16)
         c_b = "0" if st == 0 else v(sb_nxt + 16 * beta, 16)
-        E.e(f"{MFMA} {v(SA + 16 * beta, 16)}, {a(kf(q), 8)}, %[qa{st}], {c_a}, {v(ONE)}, {v(ONE)} op_sel_hi:[0,0,0]")
+        E.e(f"{MFMA} {v(SA + 16 * beta, 16)}, {v(kf(q), 8)}, %[qa{st}], {c_a}, {v(ONE)}, {v(ONE)} op_sel_hi:[0,0,0]")
         if q < LD:
             E.e(f"buffer_load_dwordx4 {v(KOFF + q)}, %[kdesc], %[ktile] offen offset:{1024 * q} lds")
         pair2(E, sb_cur + 8 * q, MCB, PB, 4 * q, LB0, LB1)
-        E.e(f"{MFMA} {v(sb_nxt + 16 * beta, 16)}, {a(kf(q), 8)}, %[qb{st}], {c_b}, {v(ONE)}, {v(ONE)} op_sel_hi:[0,0,0]")
+        E.e(f"{MFMA} {v(sb_nxt + 16 * beta, 16)}, {v(kf(q), 8)}, %[qb{st}], {c_b}, {v(ONE)}, {v(ONE)} op_sel_hi:[0,0,0]")
         pair2(E, sb_cur + 8 * q + 4, MCB, PB, 4 * q + 2, LB0, LB1)
         # look-ahead max of S_A(n+1), block 0 (complete since slice 1: >= 30 instructions ago when read in slices 2, 3)
         if q >= 2:
@@ -170,7 +170,7 @@ def gen_tile(E, slot, uid):
         if db == 0:
             E.e(f"s_add_u32 m0, %[lds_wave], {vdst}")
         E.wait_for(("v", uid, db))
-        E.e(f"{MFMA} %[oa{db}], {a(vf(db), 8)}, {v(pa_cur, 8)}, %[oa{db}], {v(ONE)}, {v(ONE)} op_sel_hi:[0,0,0]")
+        E.e(f"{MFMA} %[oa{db}], {v(vf(db), 8)}, {v(pa_cur, 8)}, %[oa{db}], {v(ONE)}, {v(ONE)} op_sel_hi:[0,0,0]")
         if db < LD:
             E.e(f"buffer_load_dwordx4 {v(VOFF + db)}, %[vdesc], %[vtile] offen offset:{1024 * db} lds")
         if db == 0:
@@ -187,7 +187,7 @@ def gen_tile(E, slot, uid):
             E.e(f"s_cbranch_vccnz .Lf8_rare_a{uid % 6}_%=")
             E.label(f".Lf8_back_a{uid % 6}_%=")
         pair2(E, SA + 8 * db, MCA, pa_nxt, 4 * db, PSA0, PSA1)
-        E.e(f"{MFMA} %[ob{db}], {a(vf(db), 8)}, {v(PB, 8)}, %[ob{db}], {v(ONE)}, {v(ONE)} op_sel_hi:[0,0,0]")
+        E.e(f"{MFMA} %[ob{db}], {v(vf(db), 8)}, {v(PB, 8)}, %[ob{db}], {v(ONE)}, {v(ONE)} op_sel_hi:[0,0,0]")
         pair2(E, SA + 8 * db + 4, MCA, pa_nxt, 4 * db + 2, PSA0, PSA1)
         # look-ahead max of S_B(n+1) (complete since the end of phase 1)
         for g in range(2):
@@ -200,6 +200,7 @@ def gen_tile(E, slot, uid):
     E.e(f"v_max_f32 {v(NXB0)}, {v(NXB0)}, {v(NXB1)}")
     E.e(f"v_add_f32 {v(PSA0)}, {v(PSA0)}, {v(PSA1)}")
     E.e(f"v_cmp_nge_f32 vcc, {v(MBT)}, {v(NXB0)}")          # !(m_b + THR / c >= max)
+    E.e(f"v_mov_b32 {v(LAS)}, {v(LA)}")                       # l_a before this tile's P_A(n+1) (the caller's phantom last tile)
     E.e(f"v_add_f32 {v(LA)}, {v(LA)}, {v(PSA0)}")
     E.e("s_add_u32 %[done], %[done], 1")
     E.e("s_or_b64 vcc, vcc, %[pend]")
@@ -286,9 +287,10 @@ HEADER = '''// GENERATED by tools/gen_fwd_loop_fp8.py -- do not edit; regenerate
 // fa::FastLoopFp8::run: the steady-state tile loop of fwd_kernel_fp8 (e4m3 inputs, head dim 128) as one inline-asm block
 // (see the generator's docstring).  Register map (arch VGPRs):
 //   v[0:31] S_A (2 blocks x 16)  v[32:63] S_B (even tiles)  v[64:95] S_B (odd)  v[96:103] P_A (even)  v[104:111] P_A (odd)
-//   v[112:119] P_B  a[224:239] K fragment double buffer  a[240:255] V^T fragment double buffer  v[168:179] LDS address registers
+//   v[112:119] P_B  v[120:135] K fragment double buffer  v[136:151] V^T fragment double buffer  v[168:179] LDS address registers
 //   v[180:183] LDS-DMA lane offsets  v184 m_a c - OFF  v185 m_b c - OFF  v186 l_a  v187 l_b  v188 m_a  v189 m_b
 //   v[190:199] temporaries / constants  v200 m_a + THR / c  v201 m_b + THR / c  v202 alpha_a handed to the caller
+//   v207 l_a before the last tile's P_A (l_a_saved)
 // O_A / O_B (8 x 16) and the Q fragments (4 x 8): AGPR tuples wherever hipcc keeps them (asm operands).
 // The block runs `count` tiles unless a guard fires: it returns at a tile boundary with `done` tiles completed, the state
 // in (sbx, pax) when `done` is even and in (sby, pay) when it is odd; pend != 0: O_A must be multiplied by alpha_a (l_a and
@@ -300,7 +302,7 @@ namespace fa {
 struct FastLoopFp8 {
     static __device__ __forceinline__ void run(f32x16 (&oa)[4], f32x16 (&ob)[4], u32x8 (&qa)[2], u32x8 (&qb)[2], f32x16 (&sa)[2],
                                                f32x16 (&sbx)[2], f32x16 (&sby)[2], u32x8 &pax, u32x8 &pay, float &l_a, float &l_b,
-                                               float &m_a, float &alpha_a, float mca, float mcb, float m_b, uint32_t kbase,
+                                               float &m_a, float &alpha_a, float &l_a_saved, float mca, float mcb, float m_b, uint32_t kbase,
                                                uint32_t vbase, const uint32_t (&koff)[2], const uint32_t (&voff)[2], float csc,
                                                float thr_c, float off, u32x4 kdesc, u32x4 vdesc, uint32_t ktile, uint32_t vtile,
                                                uint32_t kstep, uint32_t vstep, uint32_t lds0, uint32_t lds_wave, int slot0,
@@ -314,7 +316,7 @@ struct FastLoopFp8 {
               [qa0] "+a"(qa[0]), [qa1] "+a"(qa[1]), [qb0] "+a"(qb[0]), [qb1] "+a"(qb[1]),
               "=&{v[0:15]}"(sa[0]), "=&{v[16:31]}"(sa[1]), "+{v[32:47]}"(sbx[0]), "+{v[48:63]}"(sbx[1]),
               "=&{v[64:79]}"(sby[0]), "=&{v[80:95]}"(sby[1]), "+{v[96:103]}"(pax), "=&{v[104:111]}"(pay),
-              "+{v186}"(l_a), "+{v187}"(l_b), "+{v188}"(m_a), "+{v202}"(alpha_a),
+              "+{v186}"(l_a), "+{v187}"(l_b), "+{v188}"(m_a), "+{v202}"(alpha_a), "=&{v207}"(l_a_saved),
               [ktile] "+s"(ktile), [vtile] "+s"(vtile), [count] "+s"(count), [done] "+s"(done),
               [pend] "=&s"(pend), [tripb] "=&s"(tripb), [m0save] "=&s"(m0save)
             : "{v184}"(mca), "{v185}"(mcb), "{v189}"(m_b), "{v200}"(m_a + thr_c), "{v201}"(m_b + thr_c),
@@ -343,8 +345,7 @@ def render(lines):
 def main():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     path = os.path.join(root, "flash_attention_annotated_amd", "csrc", "fa_fwd_loop_fp8_gen.h")
-    clob = "".join(f', "v{i}"' for i in list(range(112, 120)) + list(range(168, 180)) + list(range(190, 200)) + [205, 206])
-    clob += "".join(f', "a{i}"' for i in range(224, 256))
+    clob = "".join(f', "v{i}"' for i in list(range(112, 152)) + list(range(168, 180)) + list(range(190, 200)) + [205, 206])
     text = HEADER % {"body": render(gen_block()), "clobbers": clob, "vregion": 3 * TILE}
     if "--check" in sys.argv:
         sys.exit(0 if os.path.exists(path) and open(path).read() == text else 1)
