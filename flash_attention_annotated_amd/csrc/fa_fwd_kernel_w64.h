@@ -472,6 +472,9 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     if (wrow >= sq || n_min >= n_max) jend = 0;
     jend = __builtin_amdgcn_readfirstlane(jend);
 
+#ifdef FA_CYCLES
+    ((unsigned long long *)(smem + 6 * BLOCK_N * D * 2 + 1024))[(threadIdx.x >> 6) * 64 + 46] = __builtin_amdgcn_s_memrealtime();
+#endif
     // ---- Q fragments (B operand of S^T = K.Q^T) -------------------------------------------------------
     // Branch-free: rows past the end are clamped to the last one and head-dim chunks past d to chunk 0, then zeroed by
     // selects.  The loads are a lane-per-row gather (32 B of each 128-B line per instruction): ~4 us until they are
@@ -1195,6 +1198,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the prefetch's LDS-DMA has landed before this workgroup's LDS is released
 #ifdef FA_CYCLES
+    ((unsigned long long *)(smem + 6 * BLOCK_N * D * 2 + 1024))[(threadIdx.x >> 6) * 64 + 47] = __builtin_amdgcn_s_memrealtime();
     __syncthreads();
     if (blockIdx.x < 256)
         fa_cycle_buf[blockIdx.x * 256 + threadIdx.x] = ((unsigned long long *)(smem + 6 * BLOCK_N * D * 2 + 1024))[threadIdx.x];

@@ -28,6 +28,9 @@ if buf[0, 0, 44] > 0:  # generated asm loop (head-dim tile 128): one stamp pair 
     print(f"asm loop: tiles requested {int(buf[0, 0, 44])}, half-steps done median {np.median(half):.0f}; cycles per 64-key tile median "
           f"{np.median(cyc / (half / 2)):.0f} (p10 {np.percentile(cyc / (half / 2), 10):.0f}, p90 {np.percentile(cyc / (half / 2), 90):.0f}; ideal 2048); "
           f"in-kernel clock {np.median(cyc / wall):.3f} GHz; block wall time {np.median(wall) / 1e3:.1f} us")
+    t0, t1, t2, t3 = (buf[:, :, k].astype(np.float64) * 0.01 for k in (46, 42, 43, 47))  # us
+    print(f"workgroup timeline (wave medians, us): entry -> block {np.median(t1 - t0):.2f} | asm block {np.median(t2 - t1):.2f} | "
+          f"block -> O stores issued {np.median(t3 - t2):.2f} | total {np.median(t3 - t0):.2f}")
 n = int(buf[0, 0, 61])
 if n < 8:
     sys.exit(0)
