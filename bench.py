@@ -80,7 +80,7 @@ def measured_traffic(workload_key):
     need the profiler); (None, None) when no counter pass has been committed for it."""
     import glob
     best, src = None, None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json"))):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic*.json"))):
         try:
             d = json.load(open(path))
         except Exception:
