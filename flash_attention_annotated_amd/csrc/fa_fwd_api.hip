@@ -386,10 +386,10 @@ int head_dim_tile(int d) {
     return 256;
 }
 
-template <typename T, int D, int NWAVES, bool SOFTCAP, bool DROPOUT = false>
+template <typename T, int D, int NWAVES, bool SOFTCAP, bool DROPOUT = false, int DEFF = D>
 int launch(const fa::KParams &kp, hipStream_t stream) {
     constexpr int smem = fa::smem_bytes<D, NWAVES>();
-    auto kernel = fa::fwd_kernel<T, D, NWAVES, SOFTCAP, DROPOUT>;
+    auto kernel = fa::fwd_kernel<T, D, NWAVES, SOFTCAP, DROPOUT, DEFF>;
     // the > 64 KiB dynamic-LDS opt-in is a per-device attribute of the kernel: one bit per device ordinal
     static std::atomic<uint64_t> attr_set{0};
     int dev = 0;
@@ -407,10 +407,10 @@ int launch(const fa::KParams &kp, hipStream_t stream) {
     return FA_OK;
 }
 
-template <typename T, int D, bool SOFTCAP>
+template <typename T, int D, bool SOFTCAP, int DEFF = D>
 int launch_w64(const fa::KParams &kp, hipStream_t stream) {
     constexpr int smem = fa::smem_bytes_w64<D>();
-    auto kernel = fa::fwd_kernel_w64<T, D, SOFTCAP>;
+    auto kernel = fa::fwd_kernel_w64<T, D, SOFTCAP, DEFF>;
     // the > 64 KiB dynamic-LDS opt-in is a per-device attribute of the kernel: one bit per device ordinal
     static std::atomic<uint64_t> attr_set{0};
     int dev = 0;
@@ -439,11 +439,16 @@ int dispatch_variant(const fa::KParams &kp, bool softcap, int variant, hipStream
         else return launch<T, D, 8, false, true>(kp, stream);
     }
     if constexpr (D == 256) {
+        // (a DEFF = 192 instantiation -- 12 + 12 instead of 16 + 16 MFMAs per 32-key block -- was measured at exactly the
+        //  per-workgroup time of the 256 one, tools/hdim_bench.py: this shape is bound by its register-staged K/V rows, which
+        //  stay 512 B wide, not by the matrix pipe; head dims 129..192 therefore keep the 256 instantiation)
         if (softcap) return launch<T, D, 4, true>(kp, stream);
         return launch<T, D, 4, false>(kp, stream);
     } else {
         if (variant == 0 || variant == 3) {
             if (softcap) return launch_w64<T, D, true>(kp, stream);
+            if constexpr (D == 128)
+                if (kp.d <= 96) return launch_w64<T, D, false, 96>(kp, stream);  // head-dim tile 96 (hopper/tile_size.h:10-54)
             return launch_w64<T, D, false>(kp, stream);
         }
         if (variant == 2) {

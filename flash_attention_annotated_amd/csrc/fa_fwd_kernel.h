@@ -239,12 +239,14 @@ __device__ __forceinline__ float max3(float a, float b, float c) {
 
 // DROPOUT is a compile-time switch: as a run-time branch its bookkeeping sat in every instantiation and cost the
 // decode shape (D = 128, 4 waves, 256-register budget) a third of its speed in extra spills.
-template <typename T, int D, int NWAVES, bool SOFTCAP, bool DROPOUT = false>
+// DEFF: head dims actually contracted / produced (<= D, multiple of 32): the k-steps and O blocks of the zero padding are
+// skipped while the LDS images keep the rows of the D tile (D = 256 with DEFF = 192: head dims 129..192, hopper/tile_size.h).
+template <typename T, int D, int NWAVES, bool SOFTCAP, bool DROPOUT = false, int DEFF = D>
 __global__ __launch_bounds__(NWAVES * 64, (D <= 128 ? 2 : 1)) void fwd_kernel(const KParams p) {
     constexpr int NT = NWAVES * 64;
     constexpr int BLOCK_M = NWAVES * 32;
-    constexpr int KSTEPS = D / 16;             // k-steps of the QK^T product
-    constexpr int DBLOCKS = D / 32;            // 32-wide blocks of the head dim (O^T row blocks)
+    constexpr int KSTEPS = DEFF / 16;          // k-steps of the QK^T product
+    constexpr int DBLOCKS = DEFF / 32;         // 32-wide blocks of the head dim (O^T row blocks)
     constexpr int CH_PER_ROW = D / 8;          // 16-byte chunks per row
     constexpr int TILE_BYTES = BLOCK_N * D * 2;
     constexpr int CHUNKS = BLOCK_N * CH_PER_ROW;

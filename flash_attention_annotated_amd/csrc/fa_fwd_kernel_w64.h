@@ -366,7 +366,9 @@ __device__ unsigned long long fa_cycle_buf[256 * 4 * 64];
 #define FA_C()
 #endif
 
-template <typename T, int D, bool SOFTCAP>
+// DEFF (head-dim tile 128 only): 96 when the head dim is <= 96 -- the generated loop then skips the k-steps and O blocks
+// of the zero padding (6 + 6 instead of 8 + 8 MFMA pairs per half-step; the LDS images keep their 256-byte rows).
+template <typename T, int D, bool SOFTCAP, int DEFF = D>
 __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     constexpr int NT = 256;
     constexpr int BLOCK_M = 256;
@@ -1017,7 +1019,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
                 unsigned long long *cb_ = (unsigned long long *)(smem + 6 * BLOCK_N * D * 2 + 1024) + (threadIdx.x >> 6) * 64;
                 cb_[40] = __builtin_amdgcn_s_memtime(); cb_[42] = __builtin_amdgcn_s_memrealtime(); cb_[44] = count;
 #endif
-                FastLoop128<T>::run(oa, ob, qa, qb, sa, sbx, sby, pax, pay, l_a, l_b, l_a_saved,
+                FastLoop128<T, DEFF>::run(oa, ob, qa, qb, sa, sbx, sby, pax, pay, l_a, l_b, l_a_saved,
                                     (m_a == -INFINITY ? 0.f : m_a) * csc, (m_b == -INFINITY ? 0.f : m_b) * csc, m_b,
                                     (uint32_t)kbase, (uint32_t)vbase, koffb, voffb, csc, THR / csc, LIM, kdesc, vdesc,
                                     ktile, vtile, (uint32_t)(BLOCK_N * k_rs * 2), (uint32_t)(BLOCK_N * v_rs * 2), lds0,

@@ -23,11 +23,18 @@ Run:  python tools/gen_fwd_loop.py  (writes the header in place; tests/test_gen_
 import os
 import sys
 
-D = 128
+D = 128                     # head-dim TILE (LDS rows of 256 B)
 ROWB = D * 2
 TILE = 64 * ROWB            # bytes of one K or V tile image
-KSTEPS = D // 16            # 8
-NSTEP = 2 * (D // 32)       # 8 (db, st) steps of the PV product
+DEFF = 128                  # head dims actually contracted / produced: 128, or 96 (k-steps and O blocks of the zero padding skipped)
+KSTEPS = DEFF // 16         # k-steps of the QK^T product (8 or 6)
+NSTEP = 2 * (DEFF // 32)    # (db, st) steps of the PV product (8 or 6)
+NPAIRS = 8                  # score pairs per 32x32 block and lane
+
+
+def pairs_of(slice_idx, nslices):
+    """score pairs whose softmax runs in slice `slice_idx` of a phase (8 pairs over 8 or 6 slices)"""
+    return [p for p in range(NPAIRS) if p * nslices // NPAIRS == slice_idx]
 LD = 4                      # LDS-DMA pieces per wave and tile
 # developer-only timing ablations (results are WRONG when non-zero; `--ablate N --out path`, never committed):
 # 1 no LDS-DMA, 2 no guard checks, 4 no max look-ahead, 8 no softmax VALU, 16 no barrier
@@ -130,7 +137,9 @@ def gen_half(E, slot, KB, uid):
             # piece ks of K tile n+3: 1 KiB at M0 + 1024 ks (the instruction offset moves the LDS target AND the source: the
             # lane offsets carry -1024 ks); rows past the end of the sequence read as zeros (raw buffer, num_records)
             E.e(f"buffer_load_dwordx4 {v(KOFF + ks)}, %[kdesc], %[ktile] offen offset:{1024 * ks} lds")
-        s0, s1 = sb_cur + 2 * ks, sb_cur + 2 * ks + 1
+        prs = pairs_of(ks, KSTEPS)
+        pr = prs[0]
+        s0, s1 = sb_cur + 2 * pr, sb_cur + 2 * pr + 1
         if not (ABLATE & 8):
             E.e(f"v_fma_f32 {v(T0)}, {v(s0)}, %[csc], -{v(MCB)}")
             E.e(f"v_fma_f32 {v(T1)}, {v(s1)}, %[csc], -{v(MCB)}")
@@ -140,8 +149,18 @@ def gen_half(E, slot, KB, uid):
         if not (ABLATE & 8):
             E.e(f"v_add_f32 {v(LB0)}, {v(LB0)}, {v(T0)}")
             E.e(f"v_add_f32 {v(LB1)}, {v(LB1)}, {v(T1)}")
-            for ins in E.cvt(PB + ks, T0, T1):
+            for ins in E.cvt(PB + pr, T0, T1):
                 E.e(ins)
+            for pr in prs[1:]:  # (DEFF = 96: 8 pairs over 6 slices)
+                s0, s1 = sb_cur + 2 * pr, sb_cur + 2 * pr + 1
+                E.e(f"v_fma_f32 {v(T0)}, {v(s0)}, %[csc], -{v(MCB)}")
+                E.e(f"v_fma_f32 {v(T1)}, {v(s1)}, %[csc], -{v(MCB)}")
+                E.e(f"v_exp_f32 {v(T0)}, {v(T0)}")
+                E.e(f"v_exp_f32 {v(T1)}, {v(T1)}")
+                E.e(f"v_add_f32 {v(LB0)}, {v(LB0)}, {v(T0)}")
+                E.e(f"v_add_f32 {v(LB1)}, {v(LB1)}, {v(T1)}")
+                for ins in E.cvt(PB + pr, T0, T1):
+                    E.e(ins)
     if KB == 0:  # K source of the next tile's DMA
         E.e("s_add_u32 %[ktile], %[ktile], %[kstep]")
     E.e(f"; ---- slot {slot} half-step KB={KB}: phase 2")
@@ -171,8 +190,11 @@ def gen_half(E, slot, KB, uid):
         E.e(f"{mf} %[oa{db}], {v(vf(t), 4)}, {v(pa_cur + 4 * st, 4)}, %[oa{db}]")
         if KB == 0 and t < LD and not (ABLATE & 1):
             E.e(f"buffer_load_dwordx4 {v(VOFF + t)}, %[vdesc], %[vtile] offen offset:{1024 * t} lds")
-        s0, s1 = SA + 2 * t, SA + 2 * t + 1
+        prs = pairs_of(t, NSTEP)
+        pr = prs[0]
+        s0, s1 = SA + 2 * pr, SA + 2 * pr + 1
         last = (t == NSTEP - 1) and not (ABLATE & 2)
+        assert not last or len(prs) == 1
         if not (ABLATE & 8):
             E.e(f"v_fma_f32 {v(T0)}, {v(s0)}, %[csc], -{v(MCA)}")
             E.e(f"v_fma_f32 {v(T1)}, {v(s1)}, %[csc], -{v(MCA)}")
@@ -190,12 +212,24 @@ def gen_half(E, slot, KB, uid):
             if last:
                 E.e("s_mov_b64 %[bflag], vcc")
                 E.e(f"v_add_f32 {v(TMP)}, {v(PSA0)}, {v(PSA1)}")
-            for ins in E.cvt(pa_nxt + t, T0, T1):
+            for ins in E.cvt(pa_nxt + pr, T0, T1):
                 E.e(ins)
-        # look-ahead max of S_B(j+1) (complete since the end of phase 1), two v_max3 per slice over slices 2..5
-        if 2 <= t <= 5 and not (ABLATE & 4):
-            i = (t - 2) * 4
-            first = (t == 2)
+            for pr in prs[1:]:
+                s0, s1 = SA + 2 * pr, SA + 2 * pr + 1
+                E.e(f"v_fma_f32 {v(T0)}, {v(s0)}, %[csc], -{v(MCA)}")
+                E.e(f"v_fma_f32 {v(T1)}, {v(s1)}, %[csc], -{v(MCA)}")
+                E.e(f"v_exp_f32 {v(T0)}, {v(T0)}")
+                E.e(f"v_exp_f32 {v(T1)}, {v(T1)}")
+                E.e(f"v_add_f32 {v(PSA0)}, {v(PSA0)}, {v(T0)}")
+                E.e(f"v_add_f32 {v(PSA1)}, {v(PSA1)}, {v(T1)}")
+                for ins in E.cvt(pa_nxt + pr, T0, T1):
+                    E.e(ins)
+        # look-ahead max of S_B(j+1) (complete since the end of phase 1), two v_max3 per slice over four slices that end
+        # two slices before the guard
+        m0_ = NSTEP - 6
+        if m0_ <= t <= m0_ + 3 and not (ABLATE & 4):
+            i = (t - m0_) * 4
+            first = (t == m0_)
             E.e(f"v_max3_f32 {v(NXA)}, {v(sb_nxt + i)}, {v(sb_nxt + i + 1)}, {v(MB) if first else v(NXA)}")
             E.e(f"v_max3_f32 {v(NXB)}, {v(sb_nxt + i + 2)}, {v(sb_nxt + i + 3)}, {v(MB) if first else v(NXB)}")
     if KB == 0:
@@ -281,10 +315,10 @@ HEADER = '''// GENERATED by tools/gen_fwd_loop.py -- do not edit; regenerate wit
 
 namespace fa {
 
-template <typename T> struct FastLoop128;
+template <typename T, int DEFF> struct FastLoop128;  // DEFF: head dims contracted / produced (128, or 96: zero padding skipped)
 '''
 
-FUNC = '''template <> struct FastLoop128<%(T)s> {
+FUNC = '''template <> struct FastLoop128<%(T)s, %(DEFF)d> {
     static __device__ __forceinline__ void run(f32x16 (&oa)[4], f32x16 (&ob)[4], u32x4 (&qa)[8], u32x4 (&qb)[8], f32x16 &sa,
                                                f32x16 &sbx, f32x16 &sby, u32x4 (&pax)[2], u32x4 (&pay)[2], float &l_a, float &l_b,
                                                float &l_a_saved, float mca, float mcb, float m_b, uint32_t kbase, uint32_t vbase,
@@ -338,10 +372,13 @@ def main():
         ABLATE = int(sys.argv[sys.argv.index("--ablate") + 1])
         path = sys.argv[sys.argv.index("--out") + 1]
     clob = "".join(f', "v{i}"' for i in list(range(64, 112)) + list(range(126, 134)))
+    global DEFF, KSTEPS, NSTEP
     text = HEADER
-    for T, mf, cvt in (("__bf16", "v_mfma_f32_32x32x16_bf16", cvt_bf16), ("_Float16", "v_mfma_f32_32x32x16_f16", cvt_f16)):
-        lines = gen_block(mf, cvt)
-        text += "\n" + FUNC % {"T": T, "body": render(lines), "clobbers": clob, "vregion": 3 * TILE}
+    for deff in (128, 96):
+        DEFF, KSTEPS, NSTEP = deff, deff // 16, 2 * (deff // 32)
+        for T, mf, cvt in (("__bf16", "v_mfma_f32_32x32x16_bf16", cvt_bf16), ("_Float16", "v_mfma_f32_32x32x16_f16", cvt_f16)):
+            lines = gen_block(mf, cvt)
+            text += "\n" + FUNC % {"T": T, "DEFF": deff, "body": render(lines), "clobbers": clob, "vregion": 3 * TILE}
     text += "\n}  // namespace fa\n"
     if "--check" in sys.argv:
         sys.exit(0 if os.path.exists(path) and open(path).read() == text else 1)
