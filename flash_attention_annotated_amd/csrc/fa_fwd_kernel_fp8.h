@@ -46,11 +46,11 @@ __device__ __forceinline__ int swz8(int row) { return (row & 6) ^ ((row >> 3) & 
 
 struct MfmaF8 {
     // hipcc pads nothing around asm MFMAs: s_nop 1 in front covers VALU-written operands, callers drain before VALU reads results
-    static __device__ __forceinline__ void s_first(f32x16 &d, u32x8 k, u32x8 &q, uint32_t one) {
-        asm("s_nop 1\n\tv_mfma_scale_f32_32x32x64_f8f6f4 %0, %2, %1, 0, %3, %3 op_sel_hi:[0,0,0]" : "=&v"(d), "+a"(q) : "v"(k), "v"(one));
+    static __device__ __forceinline__ void s_first(f32x16 &d, u32x8 k, const u32x8 &q, uint32_t one) {
+        asm("s_nop 1\n\tv_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, 0, %3, %3 op_sel_hi:[0,0,0]" : "=&v"(d) : "v"(k), "v"(q), "v"(one));
     }
-    static __device__ __forceinline__ void s_acc(f32x16 &d, u32x8 k, u32x8 &q, uint32_t one) {
-        asm("s_nop 1\n\tv_mfma_scale_f32_32x32x64_f8f6f4 %0, %2, %1, %0, %3, %3 op_sel_hi:[0,0,0]" : "+v"(d), "+a"(q) : "v"(k), "v"(one));
+    static __device__ __forceinline__ void s_acc(f32x16 &d, u32x8 k, const u32x8 &q, uint32_t one) {
+        asm("s_nop 1\n\tv_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+v"(d) : "v"(k), "v"(q), "v"(one));
     }
     static __device__ __forceinline__ void o_acc(f32x16 &o, u32x8 vf, u32x8 pf, uint32_t one) {
         asm("s_nop 1\n\tv_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+a"(o) : "v"(vf), "v"(pf), "v"(one));
@@ -334,24 +334,57 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_fp8(const KParams p) {
             qb[st] = row_b < sq ? qb[st] : z8;
         }
     }
-#pragma unroll
-    for (int st = 0; st < 2; ++st) {
-        asm volatile("; pin Q" : "+a"(qa[st]));
-        asm volatile("; pin Q" : "+a"(qb[st]));
-    }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
-    f32x16 sa[2], sbx[2];
-    u32x8 pax = {0, 0, 0, 0, 0, 0, 0, 0}, pb = pax;
+    // The pipeline state between tiles -- S_B(n) (32 raw scores per lane) and P_A(n) (8 dwords) -- lives in a per-wave LDS
+    // hand-off area behind the K/V rings (10 x 16 B per lane, chunk c of lane l at st + 1024 c), never in loop-carried
+    // registers: the generated block reads / writes it there, the boundary code loads it where it needs it.  (As 40
+    // loop-carried registers it was spilled to scratch around every entry of the block, whose register map is fixed.)
+    char *st = smem + 6 * TILE_BYTES + wave * (10 * 1024) + lane * 16;
+    auto state_store = [&](const f32x16 (&sb)[2], const u32x8 &pa) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            u32x4 w;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[e] = __float_as_uint(sb[c >> 2][4 * (c & 3) + e]);
+            *(u32x4 *)(st + 1024 * c) = w;
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            u32x4 w;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[e] = pa[4 * c + e];
+            *(u32x4 *)(st + 1024 * (8 + c)) = w;
+        }
+    };
+    auto state_load_sb = [&](f32x16 (&sb)[2]) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const u32x4 w = *(const u32x4 *)(st + 1024 * c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sb[c >> 2][4 * (c & 3) + e] = __uint_as_float(w[e]);
+        }
+    };
+    auto state_load_pa = [&](u32x8 &pa) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const u32x4 w = *(const u32x4 *)(st + 1024 * (8 + c));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pa[4 * c + e] = w[e];
+        }
+    };
     float alpha_a = 1.f, alpha_b = 1.f;
     bool moved_a = false, moved_b = false;
     if (tend > 0) {
-        qk_tile(0, sa, sbx);
-        drain_scores(sa, sbx);
-        mask_scores(0, sa, sbx);
-        softmax(sa, pax, m_a, l_a, alpha_a, moved_a);
+        f32x16 sa[2], sb[2];
+        u32x8 pa;
+        qk_tile(0, sa, sb);
+        drain_scores(sa, sb);
+        mask_scores(0, sa, sb);
+        softmax(sa, pa, m_a, l_a, alpha_a, moved_a);
         moved_a = false;  // O_A is still zero
-        m_b = rowmax32(sbx, m_b);  // B's running max starts at the max of its first tile (l_b stays 0)
+        m_b = rowmax32(sb, m_b);  // B's running max starts at the max of its first tile (l_b stays 0)
+        state_store(sb, pa);
     }
     __syncthreads();  // every wave has read K tile 0 before tile 0's DMA overwrites its slot
 
@@ -363,15 +396,24 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_fp8(const KParams p) {
         if (i < tend) {
             if (moved_a) rescale(oa, alpha_a);
             moved_a = false;
-            softmax(sbx, pb, m_b, l_b, alpha_b, moved_b);
-            if (moved_b) rescale(ob, alpha_b);
-            pv_tile(slot, pax, pb);
-            drain_all();
+            {
+                f32x16 sb[2];
+                u32x8 pa, pb;
+                state_load_sb(sb);
+                softmax(sb, pb, m_b, l_b, alpha_b, moved_b);
+                if (moved_b) rescale(ob, alpha_b);
+                state_load_pa(pa);
+                pv_tile(slot, pa, pb);
+                drain_all();
+            }
             if (i + 1 < tend) {
-                qk_tile(slot1, sa, sbx);
-                drain_scores(sa, sbx);
-                mask_scores(i + 1, sa, sbx);
-                softmax(sa, pax, m_a, l_a, alpha_a, moved_a);
+                f32x16 sa[2], sb[2];
+                u32x8 pa;
+                qk_tile(slot1, sa, sb);
+                drain_scores(sa, sb);
+                mask_scores(i + 1, sa, sb);
+                softmax(sa, pa, m_a, l_a, alpha_a, moved_a);
+                state_store(sb, pa);
             }
         }
         asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -401,7 +443,9 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_fp8(const KParams p) {
         if (count >= 1 && !moved_a && (int64_t)sk * k_rs < (1ll << 31) && (int64_t)sk * v_rs < (1ll << 31) &&
             !__any(m_a == -INFINITY || m_b == -INFINITY)) {
             {   // S_B(i) must be safe to exponentiate with the stale m_b (inside the block the look-ahead guarantees it)
-                const float m_new = rowmax32(sbx, m_b);
+                f32x16 sb[2];
+                state_load_sb(sb);
+                const float m_new = rowmax32(sb, m_b);
                 if (__any((m_new - m_b) * csc > THR)) {
                     const float al = __builtin_amdgcn_exp2f((m_b - m_new) * csc);
                     rescale(ob, al);
@@ -412,19 +456,13 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_fp8(const KParams p) {
             int done = 0;
             uint64_t pend = 0, tripb = 0;
             float ala = 1.f, l_a_saved = l_a;
-            f32x16 sby[2];
-            u32x8 pay;
-            FastLoopFp8::run(oa, ob, qa, qb, sa, sbx, sby, pax, pay, l_a, l_b, m_a, ala, l_a_saved, m_a * csc - OFF,
-                             m_b * csc - OFF, m_b, (uint32_t)kbase, (uint32_t)vbase, koff, voff, csc,
+            FastLoopFp8::run(oa, ob, qa, qb, lds0 + 6 * TILE_BYTES + wave * (10 * 1024) + lane * 16, l_a, l_b, m_a, ala, l_a_saved,
+                             m_a * csc - OFF, m_b * csc - OFF, m_b, (uint32_t)kbase, (uint32_t)vbase, koff, voff, csc,
                              phantom ? INFINITY : THR / csc, OFF, kdesc, vdesc,
                              (uint32_t)((i + 3) * BLOCK_N * k_rs), (uint32_t)((i + 2) * BLOCK_N * v_rs),
                              (uint32_t)(BLOCK_N * k_rs), (uint32_t)(BLOCK_N * v_rs), lds0, lds_wave, i % 3, count, done,
                              pend, tripb);
             i += done;
-            if (done & 1) {
-                sbx[0] = sby[0]; sbx[1] = sby[1];
-                pax = pay;
-            }
             if (phantom) l_a = l_a_saved;
             if (pend != 0) rescale(oa, ala);
             (void)tripb;  // q-block B's new max is taken at the top of the next iteration (or by the generic tile)
@@ -485,6 +523,6 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_fp8(const KParams p) {
     }
 }
 
-constexpr int smem_bytes_fp8() { return 4 * 64 * (128 * 2 + 16); }  // the O staging (69632 B) covers the K/V rings (48 KiB)
+constexpr int smem_bytes_fp8() { return 6 * 64 * 128 + 4 * 10 * 1024; }  // K/V rings (48 KiB) + the state hand-off area (40 KiB); the O staging (68 KiB) reuses them
 
 }  // namespace fa

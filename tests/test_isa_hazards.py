@@ -39,12 +39,11 @@ def test_no_unpadded_mfma_or_trans_hazards(tmp_path, unit):
                 if "scratch_load" in l and 0 < n < total:
                     inside.append(n)
         if "fwd_kernel_fp8" in name:
-            # the steady-state tile loop is the generated asm block: no scratch instruction between its first tile label and
-            # its exit label (the boundary code around it -- prologue, masked tiles, rescales, run a few times per workgroup
-            # -- still spills some of its 96 score registers around the block's fixed register map)
+            # no scratch at all (the pipeline state crosses tile boundaries through LDS, not through loop-carried registers
+            # that hipcc would have to save around the generated block's fixed register map)
+            assert any_scratch == 0, (name, any_scratch)
             body = "\n".join(lines)
             i0, i1 = body.index(".Lf8_t0_"), body.rindex(".Lf8_exit_")
-            assert "scratch_" not in body[i0:i1], name
             assert body[i0:i1].count("v_mfma") == 96, name  # 6 unrolled tiles x 16
         elif "fwd_kernel_w64" in name:
             assert any_scratch == 0, (name, any_scratch)

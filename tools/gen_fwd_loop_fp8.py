@@ -42,7 +42,7 @@ KA, VA = 168, 172                   # 4 + 8 LDS address registers
 KOFF, VOFF = 180, 182
 MCA, MCB, LA, LB0, MA, MB = 184, 185, 186, 187, 188, 189
 T0, T1, T2, T3, NXA0, NXA1, NXB0, NXB1 = 190, 191, 192, 193, 194, 195, 196, 197
-LB1, ONE, MAT, MBT, ALA, KBASE, VBASE, PSA0, PSA1, LAS = 198, 199, 200, 201, 202, 203, 204, 205, 206, 207
+LB1, ONE, MAT, MBT, ALA, KBASE, VBASE, PSA0, PSA1, LAS, STB = 198, 199, 200, 201, 202, 203, 204, 205, 206, 207, 208
 MFMA = "v_mfma_scale_f32_32x32x64_f8f6f4"
 
 
@@ -230,6 +230,15 @@ def gen_block():
         E.e(f"v_add_u32 {v(VA + i)}, %[lds0v], {v(VA + i)}")
     E.e(f"v_mov_b32 {v(LB1)}, 0")
     E.e(f"v_mov_b32 {v(ONE)}, 0x7f7f7f7f")
+    # pipeline state in: S_B(n) (32 scores) and P_A(n) (8 dwords) come through a per-wave LDS hand-off area (10 x 16 B per
+    # lane, chunk c of lane l at STB + 1024 c) instead of 40 fixed-register operands: hipcc then keeps none of it live in
+    # registers across the block (with them bound to v[32:63] / v[96:103] it spilled ~70 registers per lane to scratch around
+    # every entry)
+    for c in range(8):
+        E.e(f"ds_read_b128 {v(SBX + 4 * c, 4)}, {v(STB)} offset:{1024 * c}")
+    for c in range(2):
+        E.e(f"ds_read_b128 {v(PAX + 4 * c, 4)}, {v(STB)} offset:{1024 * (8 + c)}")
+    E.e("s_waitcnt lgkmcnt(0)")
     # entry: first K fragment pair of the first tile, from K ring slot (slot0 + 1) % 3.  The body below is unrolled over the
     # three ring slots x the two (SBX/SBY, PAX/PAY) role parities = 6 tiles; the caller enters with parity 0 state, so the
     # entry slot picks one of the three even positions: position p = slot0 handles slot p % 3 with parity p & 1 -> enter at
@@ -274,6 +283,21 @@ def gen_block():
     E.e("s_mov_b64 %[tripb], vcc")
     E.label(f".Lf8_exit_{u}")
     E.e("s_waitcnt lgkmcnt(0)")
+    # pipeline state out, from the buffers of the parity the block stopped at
+    E.e("s_bitcmp1_b32 %[done], 0")
+    E.e(f"s_cbranch_scc1 .Lf8_out_odd_{u}")
+    for c in range(8):
+        E.e(f"ds_write_b128 {v(STB)}, {v(SBX + 4 * c, 4)} offset:{1024 * c}")
+    for c in range(2):
+        E.e(f"ds_write_b128 {v(STB)}, {v(PAX + 4 * c, 4)} offset:{1024 * (8 + c)}")
+    E.e(f"s_branch .Lf8_out_done_{u}")
+    E.label(f".Lf8_out_odd_{u}")
+    for c in range(8):
+        E.e(f"ds_write_b128 {v(STB)}, {v(SBY + 4 * c, 4)} offset:{1024 * c}")
+    for c in range(2):
+        E.e(f"ds_write_b128 {v(STB)}, {v(PAY + 4 * c, 4)} offset:{1024 * (8 + c)}")
+    E.label(f".Lf8_out_done_{u}")
+    E.e("s_waitcnt lgkmcnt(0)")
     E.e(f"v_add_f32 {v(LB0)}, {v(LB0)}, {v(LB1)}")
     E.e("s_nop 15")
     E.e("s_nop 15")
@@ -291,17 +315,19 @@ HEADER = '''// GENERATED by tools/gen_fwd_loop_fp8.py -- do not edit; regenerate
 //   v[180:183] LDS-DMA lane offsets  v184 m_a c - OFF  v185 m_b c - OFF  v186 l_a  v187 l_b  v188 m_a  v189 m_b
 //   v[190:199] temporaries / constants  v200 m_a + THR / c  v201 m_b + THR / c  v202 alpha_a handed to the caller
 //   v207 l_a before the last tile's P_A (l_a_saved)
-// O_A / O_B (8 x 16) and the Q fragments (4 x 8): AGPR tuples wherever hipcc keeps them (asm operands).
-// The block runs `count` tiles unless a guard fires: it returns at a tile boundary with `done` tiles completed, the state
-// in (sbx, pax) when `done` is even and in (sby, pay) when it is odd; pend != 0: O_A must be multiplied by alpha_a (l_a and
+// O_A / O_B (8 x 16): AGPR tuples wherever hipcc keeps them; the Q fragments (4 x 8): VGPR tuples of hipcc's choice (the
+// block leaves v[152:167] and v[209:255] alone) -- pinned in AGPRs they were spilled to scratch around the boundary code.
+// The pipeline state -- S_B(n) (32 scores per lane) and P_A(n) (8 dwords) -- enters and leaves through a per-wave LDS
+// hand-off area: chunk c (16 B) of lane l at state_lds + 1024 c, state_lds = area base + 16 l, chunks 0..7 = S_B, 8..9 = P_A.
+// The block runs `count` tiles unless a guard fires: it returns at a tile boundary with `done` tiles completed; pend != 0: O_A must be multiplied by alpha_a (l_a and
 // m_a are already updated); tripb != 0: q-block B needs a fresh max before S_B of the next tile is exponentiated.
 #pragma once
 
 namespace fa {
 
 struct FastLoopFp8 {
-    static __device__ __forceinline__ void run(f32x16 (&oa)[4], f32x16 (&ob)[4], u32x8 (&qa)[2], u32x8 (&qb)[2], f32x16 (&sa)[2],
-                                               f32x16 (&sbx)[2], f32x16 (&sby)[2], u32x8 &pax, u32x8 &pay, float &l_a, float &l_b,
+    static __device__ __forceinline__ void run(f32x16 (&oa)[4], f32x16 (&ob)[4], const u32x8 (&qa)[2], const u32x8 (&qb)[2],
+                                               uint32_t state_lds, float &l_a, float &l_b,
                                                float &m_a, float &alpha_a, float &l_a_saved, float mca, float mcb, float m_b, uint32_t kbase,
                                                uint32_t vbase, const uint32_t (&koff)[2], const uint32_t (&voff)[2], float csc,
                                                float thr_c, float off, u32x4 kdesc, u32x4 vdesc, uint32_t ktile, uint32_t vtile,
@@ -313,17 +339,14 @@ struct FastLoopFp8 {
 %(body)s
             : [oa0] "+a"(oa[0]), [oa1] "+a"(oa[1]), [oa2] "+a"(oa[2]), [oa3] "+a"(oa[3]),
               [ob0] "+a"(ob[0]), [ob1] "+a"(ob[1]), [ob2] "+a"(ob[2]), [ob3] "+a"(ob[3]),
-              [qa0] "+a"(qa[0]), [qa1] "+a"(qa[1]), [qb0] "+a"(qb[0]), [qb1] "+a"(qb[1]),
-              "=&{v[0:15]}"(sa[0]), "=&{v[16:31]}"(sa[1]), "+{v[32:47]}"(sbx[0]), "+{v[48:63]}"(sbx[1]),
-              "=&{v[64:79]}"(sby[0]), "=&{v[80:95]}"(sby[1]), "+{v[96:103]}"(pax), "=&{v[104:111]}"(pay),
               "+{v186}"(l_a), "+{v187}"(l_b), "+{v188}"(m_a), "+{v202}"(alpha_a), "=&{v207}"(l_a_saved),
               [ktile] "+s"(ktile), [vtile] "+s"(vtile), [count] "+s"(count), [done] "+s"(done),
               [pend] "=&s"(pend), [tripb] "=&s"(tripb), [m0save] "=&s"(m0save)
             : "{v184}"(mca), "{v185}"(mcb), "{v189}"(m_b), "{v200}"(m_a + thr_c), "{v201}"(m_b + thr_c),
-              "{v203}"(kbase), "{v204}"(vbase), "{v180}"(koff[0]), "{v181}"(koff[1]), "{v182}"(voff[0]), "{v183}"(voff[1]),
+              "{v203}"(kbase), "{v204}"(vbase), "{v208}"(state_lds), "{v180}"(koff[0]), "{v181}"(koff[1]), "{v182}"(voff[0]), "{v183}"(voff[1]),
               [csc] "s"(csc), [thr_c] "s"(thr_c), [off] "s"(off), [kstep] "s"(kstep), [vstep] "s"(vstep),
               [kdesc] "s"(kdesc), [vdesc] "s"(vdesc), [lds0] "s"(lds0), [lds0v] "s"(lds0v), [lds_wave] "s"(lds_wave),
-              [slot0] "s"(slot0)
+              [slot0] "s"(slot0), [qa0] "v"(qa[0]), [qa1] "v"(qa[1]), [qb0] "v"(qb[0]), [qb1] "v"(qb[1])
             : "memory", "vcc", "scc"%(clobbers)s);
     }
 };
@@ -345,7 +368,7 @@ def render(lines):
 def main():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     path = os.path.join(root, "flash_attention_annotated_amd", "csrc", "fa_fwd_loop_fp8_gen.h")
-    clob = "".join(f', "v{i}"' for i in list(range(112, 152)) + list(range(168, 180)) + list(range(190, 200)) + [205, 206])
+    clob = "".join(f', "v{i}"' for i in list(range(0, 152)) + list(range(168, 180)) + list(range(190, 200)) + [205, 206])
     text = HEADER % {"body": render(gen_block()), "clobbers": clob, "vregion": 3 * TILE}
     if "--check" in sys.argv:
         sys.exit(0 if os.path.exists(path) and open(path).read() == text else 1)
