@@ -950,6 +950,8 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
         fast_last = min(nomask, jend - 1);
     }
     fast_last = __builtin_amdgcn_readfirstlane(fast_last);
+    // masks the generated block can apply itself: sequence end, causal / right window (no left window, ALiBi or softcap)
+    const bool mask_ok = !SOFTCAP && p.window_left < 0 && jend > 0 && !p.alibi;
 
     // Driver.  ONE call site of generic_half (its body is large; inlining it twice wrecks register allocation).
     auto to_canonical_after_odd = [&]() {  // after a KB = 0 fast half-step the next scores / P_A live in sby / pay
@@ -965,14 +967,14 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     bool first = true;  // the prologue leaves the pipeline state a fast tile expects: tile 0 may go straight to the fast loop
     while (j < J) {
         // generic until the next tile boundary (at least one half-step, except in front of tile 0: guarantees progress)
-        if (!(first && tile_ok(0))) {
+        if (!(first && (tile_ok(0) || (mask_ok && D == 128 && jend > 0)))) {
             do {
                 generic_half(j);
                 ++j;
             } while ((j & 1) != 0 && j < J);
         }
         first = false;
-        if (!tile_ok(j) || moved_a || redo_a) continue;
+        if ((!tile_ok(j) && !(mask_ok && D == 128 && (j & 1) == 0 && j < jend)) || moved_a || redo_a) continue;
         {   // B(j) must be safe to exponentiate with its stale max (inside the loop the look-ahead guarantees it)
             float xa, xb;
             rowmax16(sbx, m_b, xa, xb);
@@ -983,15 +985,11 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
         // three or so mask-free tiles, whose look-ahead rows have to be clamped) goes through the C++ form below.
         bool tripped = false;
         if constexpr (D == 128 && !SOFTCAP && !(FA_ABLATE & 32)) {
-            const int n_cur = n_min + (j >> 1);
-            // tiles jt = j, j + 2, .. with jt + 2 <= fast_last -- plus the wave's LAST tile when its own half-steps need no mask
-            // (`phantom`): the block then also forms S(jend) / P_A(jend) from whatever K tile follows (real keys behind a causal
-            // diagonal or the zeros that rows past the end of the sequence read as); nothing of that is used, and the
-            // one thing it touches, l_a, is restored from l_a_saved below.
-            const bool phantom = fast_last == jend - 1 && (jend & 1) == 0 && jend - j >= 2 && !(FA_ABLATE & 64);
-            int count = phantom ? (jend - j) >> 1 : (fast_last - j) >> 1;
             // (the descriptors address bytes with 32 bits: longer sequences stay on the C++ form)
-            if (count >= 2 && (int64_t)sk * k_rs64 < (1ll << 30) && (int64_t)sk * v_rs64 < (1ll << 30)) {
+            const bool addr32 = (int64_t)sk * k_rs64 < (1ll << 30) && (int64_t)sk * v_rs64 < (1ll << 30);
+            auto run_block = [&](auto masked_c, int count, bool restore_la) {
+                constexpr bool MASKED = decltype(masked_c)::value;
+                const int n_cur = n_min + (j >> 1);
                 auto make_desc = [&](const T *base, int64_t rs64) {
                     const uint64_t b = (uint64_t)(uintptr_t)base;
                     u32x4 dsc;
@@ -1013,32 +1011,54 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
                 const uint32_t ktile = (uint32_t)(((n_cur + 3) * BLOCK_N - 32) * k_rs * 2);
                 const uint32_t vtile = (uint32_t)((n_cur + 2) * BLOCK_N * v_rs * 2);
                 const float csc = csc_arg;
-                int done = 0;
+                int done = 0, ra = 0, rb = 0;
                 uint64_t redo = 0;
+                if constexpr (MASKED) {  // last visible key of this lane's rows, relative to the key base of S(j+1) in its lane half
+                    const int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+                    const int kb1 = n_min * BLOCK_N + 32 * (j + 1) + 4 * (ln >> 5);
+                    const int row = wrow + (ln & 31) + shift;
+                    ra = (p.window_right >= 0 ? min(sk - 1, row + p.window_right) : sk - 1) - kb1;
+                    rb = (p.window_right >= 0 ? min(sk - 1, row + 32 + p.window_right) : sk - 1) - kb1;
+                }
 #ifdef FA_CYCLES
                 unsigned long long *cb_ = (unsigned long long *)(smem + 6 * BLOCK_N * D * 2 + 1024) + (threadIdx.x >> 6) * 64;
-                cb_[40] = __builtin_amdgcn_s_memtime(); cb_[42] = __builtin_amdgcn_s_memrealtime(); cb_[44] = count;
+                if (!MASKED) { cb_[40] = __builtin_amdgcn_s_memtime(); cb_[42] = __builtin_amdgcn_s_memrealtime(); cb_[44] = count; }
 #endif
-                FastLoop128<T, DEFF>::run(oa, ob, qa, qb, sa, sbx, sby, pax, pay, l_a, l_b, l_a_saved,
-                                    (m_a == -INFINITY ? 0.f : m_a) * csc, (m_b == -INFINITY ? 0.f : m_b) * csc, m_b,
-                                    (uint32_t)kbase, (uint32_t)vbase, koffb, voffb, csc, THR / csc, LIM, kdesc, vdesc,
-                                    ktile, vtile, (uint32_t)(BLOCK_N * k_rs * 2), (uint32_t)(BLOCK_N * v_rs * 2), lds0,
-                                    lds_wave, (j >> 1) % 3, count, done, redo);
+                FastLoop128<T, DEFF, MASKED>::run(oa, ob, qa, qb, sa, sbx, sby, pax, pay, l_a, l_b, l_a_saved,
+                                                  (m_a == -INFINITY ? 0.f : m_a) * csc, (m_b == -INFINITY ? 0.f : m_b) * csc, m_b,
+                                                  (uint32_t)kbase, (uint32_t)vbase, koffb, voffb, csc, THR / csc, LIM, kdesc,
+                                                  vdesc, ktile, vtile, (uint32_t)(BLOCK_N * k_rs * 2),
+                                                  (uint32_t)(BLOCK_N * v_rs * 2), lds0, lds_wave, (j >> 1) % 3, count, done,
+                                                  redo, ra, rb);
 #ifdef FA_CYCLES
-                cb_[41] = __builtin_amdgcn_s_memtime(); cb_[43] = __builtin_amdgcn_s_memrealtime(); cb_[45] = done;
+                if (!MASKED) { cb_[41] = __builtin_amdgcn_s_memtime(); cb_[43] = __builtin_amdgcn_s_memrealtime(); cb_[45] = done; }
 #endif
                 j += done;
                 in_flight = 2 * LD_PER_THREAD;
                 redo_a = redo != 0;
-                if (phantom && j == jend) {
-                    l_a = l_a_saved;
-                    redo_a = false;
-                }
                 if (count != 0) {  // a guard tripped: the next half-step is the generic path's
                     tripped = true;
                     if (done & 1) to_canonical_after_odd();
+                } else if (restore_la) {  // the block's last half-step formed a phantom P_A: only l_a saw it
+                    l_a = l_a_saved;
+                    redo_a = false;
                 }
+            };
+            // (1) The bulk of the sweep: every run of >= 2 mask-free tiles -- including the wave's LAST tile when its own
+            // half-steps need no mask (`phantom`: the block then also forms S(jend) / P_A(jend) from whatever K tile follows,
+            // real keys behind a causal diagonal or the zeros that rows past the end of the sequence read as; nothing of that
+            // is used, and the one thing it touches, l_a, is restored from l_a_saved).
+            if (addr32 && tile_ok(j)) {
+                const bool phantom = fast_last == jend - 1 && (jend & 1) == 0 && jend - j >= 2 && !(FA_ABLATE & 64);
+                const int count = phantom ? (jend - j) >> 1 : (fast_last - j) >> 1;
+                if (count >= 2) run_block(std::false_type{}, count, phantom);
             }
+            // (2) What is left of this wave's tiles -- the diagonal tiles under a causal / right-window mask, the tail tile of a
+            // sequence that is not a multiple of 64 -- in the MASKED form of the block (the fresh scores get the mask, two
+            // VALU instructions per score, before anything reads them).  Whole tiles: a trailing half-step the wave does not
+            // need is fully masked and contributes exact zeros; the last half-step's P_A is a phantom as above.
+            if (addr32 && mask_ok && !tripped && (j & 1) == 0 && j < jend && !(FA_ABLATE & 128))
+                run_block(std::true_type{}, (jend + 1 - j) >> 1, true);
         }
         // fast: up to three tiles (one turn of the LDS rings) per iteration; the first turn starts at the ring slot of
         // tile j/2 (`skip` slots are already behind us); every fast tile issues 2 LD_PER_THREAD LDS-DMA pieces, one per

@@ -30,6 +30,11 @@ DEFF = 128                  # head dims actually contracted / produced: 128, or 
 KSTEPS = DEFF // 16         # k-steps of the QK^T product (8 or 6)
 NSTEP = 2 * (DEFF // 32)    # (db, st) steps of the PV product (8 or 6)
 NPAIRS = 8                  # score pairs per 32x32 block and lane
+MASKED = False              # variant with the causal / right-window / end-of-sequence mask applied to the fresh scores
+
+
+def keyoff(i):
+    return (i & 3) + 8 * (i >> 2)   # key of accumulator register i inside its 32-key block (+ 4 per lane half)
 
 
 def pairs_of(slice_idx, nslices):
@@ -49,6 +54,7 @@ KOFF, VOFF = 112, 116
 MCA, MCB, LA, LB0, LAS, MB = 120, 121, 122, 123, 124, 125
 T0, T1, PSA0, PSA1, NXA, NXB, TMP, LB1 = 126, 127, 128, 129, 130, 131, 132, 133
 KBASE, VBASE, MBT = 134, 135, 136
+RA, RB, NINF = 137, 138, 139   # MASKED variant: per-lane key limits relative to the next half-step's key base, -inf
 # ---- AGPRs ----
 OA, OB, QA, QB = 0, 64, 128, 160
 
@@ -190,6 +196,17 @@ def gen_half(E, slot, KB, uid):
         E.e(f"{mf} %[oa{db}], {v(vf(t), 4)}, {v(pa_cur + 4 * st, 4)}, %[oa{db}]")
         if KB == 0 and t < LD and not (ABLATE & 1):
             E.e(f"buffer_load_dwordx4 {v(VOFF + t)}, %[vdesc], %[vtile] offen offset:{1024 * t} lds")
+        if MASKED and t == 0:
+            # mask of S_A(j+1) (complete since the last MFMA A of phase 1), before its first score is exponentiated: register i
+            # is key base + keyoff(i); masked iff keyoff(i) > RA = (last visible key of this lane's row A) - key base
+            for i in range(16):
+                E.e(f"v_cmp_gt_i32 vcc, {keyoff(i)}, {v(RA)}")
+                E.e(f"v_cndmask_b32 {v(SA + i)}, {v(SA + i)}, {v(NINF)}, vcc")
+        if MASKED and t < 4:
+            # mask of S_B(j+1), four registers per slice, ahead of the look-ahead max that reads them two slices later
+            for i in range(4 * t, 4 * t + 4):
+                E.e(f"v_cmp_gt_i32 vcc, {keyoff(i)}, {v(RB)}")
+                E.e(f"v_cndmask_b32 {v(sb_nxt + i)}, {v(sb_nxt + i)}, {v(NINF)}, vcc")
         prs = pairs_of(t, NSTEP)
         pr = prs[0]
         s0, s1 = SA + 2 * pr, SA + 2 * pr + 1
@@ -227,6 +244,8 @@ def gen_half(E, slot, KB, uid):
         # look-ahead max of S_B(j+1) (complete since the end of phase 1), two v_max3 per slice over four slices that end
         # two slices before the guard
         m0_ = NSTEP - 6
+        if MASKED:
+            m0_ = max(m0_, 1)  # (registers 4k..4k+3 are masked in slice k: read them from slice k+1 on)
         if m0_ <= t <= m0_ + 3 and not (ABLATE & 4):
             i = (t - m0_) * 4
             first = (t == m0_)
@@ -234,6 +253,9 @@ def gen_half(E, slot, KB, uid):
             E.e(f"v_max3_f32 {v(NXB)}, {v(sb_nxt + i + 2)}, {v(sb_nxt + i + 3)}, {v(MB) if first else v(NXB)}")
     if KB == 0:
         E.e("s_add_u32 %[vtile], %[vtile], %[vstep]")
+    if MASKED:  # the next half-step's scores start 32 keys further on
+        E.e(f"v_subrev_u32 {v(RA)}, 32, {v(RA)}")
+        E.e(f"v_subrev_u32 {v(RB)}, 32, {v(RB)}")
     # ---- guards (rare exits): guard A = the partial row sums of P_A(j+1) ----
     E.e("s_add_u32 %[done], %[done], 1")
     if ABLATE & 2:
@@ -260,6 +282,8 @@ def gen_block(mfma, cvt):
         E.e(f"v_add_u32 {v(KA + i)}, %[lds0], {v(KA + i)}")
         E.e(f"v_add_u32 {v(VA + i)}, %[lds0v], {v(VA + i)}")
     E.e(f"v_mov_b32 {v(LB1)}, 0")
+    if MASKED:
+        E.e(f"v_mov_b32 {v(NINF)}, 0xff800000")
     # entry: first two K fragments of the first half-step, from K ring slot (slot0 + 1) % 3
     E.e("s_cmp_eq_u32 %[slot0], 1")
     E.e(f"s_cbranch_scc1 .Lfa_in1_{u}")
@@ -315,17 +339,20 @@ HEADER = '''// GENERATED by tools/gen_fwd_loop.py -- do not edit; regenerate wit
 
 namespace fa {
 
-template <typename T, int DEFF> struct FastLoop128;  // DEFF: head dims contracted / produced (128, or 96: zero padding skipped)
+template <typename T, int DEFF, bool MASKED = false> struct FastLoop128;
+// DEFF: head dims contracted / produced (128, or 96: zero padding skipped).  MASKED: the fresh scores S_A(j+1) / S_B(j+1) get
+// the causal / right-window / end-of-sequence mask (key > limit -> -inf; ra / rb = the lane's last visible key minus the key
+// base 64 n_min + 32 (j+1) + 4 (lane >> 5) of the first half-step's NEXT scores): the diagonal and tail tiles of a wave.
 '''
 
-FUNC = '''template <> struct FastLoop128<%(T)s, %(DEFF)d> {
+FUNC = '''template <> struct FastLoop128<%(T)s, %(DEFF)d, %(MASKED)s> {
     static __device__ __forceinline__ void run(f32x16 (&oa)[4], f32x16 (&ob)[4], u32x4 (&qa)[8], u32x4 (&qb)[8], f32x16 &sa,
                                                f32x16 &sbx, f32x16 &sby, u32x4 (&pax)[2], u32x4 (&pay)[2], float &l_a, float &l_b,
                                                float &l_a_saved, float mca, float mcb, float m_b, uint32_t kbase, uint32_t vbase,
                                                const uint32_t (&koff)[4], const uint32_t (&voff)[4], float csc, float thr_c,
                                                float lim, u32x4 kdesc, u32x4 vdesc, uint32_t ktile, uint32_t vtile,
                                                uint32_t kstep, uint32_t vstep, uint32_t lds0, uint32_t lds_wave, int slot0,
-                                               int &count, int &done, uint64_t &redo) {
+                                               int &count, int &done, uint64_t &redo, int ra = 0, int rb = 0) {
         uint32_t m0save;
         uint64_t bflag;
         const uint32_t lds0v = lds0 + %(vregion)d;
@@ -341,7 +368,7 @@ FUNC = '''template <> struct FastLoop128<%(T)s, %(DEFF)d> {
               "+{v[48:51]}"(pax[0]), "+{v[52:55]}"(pax[1]), "+{v[56:59]}"(pay[0]), "+{v[60:63]}"(pay[1]),
               "+{v122}"(l_a), "+{v123}"(l_b), "+{v124}"(l_a_saved),
               [ktile] "+s"(ktile), [vtile] "+s"(vtile),
-              [count] "+s"(count), [done] "+s"(done), [redo] "=&s"(redo), [bflag] "=&s"(bflag), [m0save] "=&s"(m0save)
+              [count] "+s"(count), [done] "+s"(done), [redo] "=&s"(redo), [bflag] "=&s"(bflag), [m0save] "=&s"(m0save)%(maskout)s
             : "{v120}"(mca), "{v121}"(mcb), "{v125}"(m_b), "{v136}"(m_b + thr_c), "{v134}"(kbase), "{v135}"(vbase),
               "{v112}"(koff[0]), "{v113}"(koff[1]), "{v114}"(koff[2]), "{v115}"(koff[3]),
               "{v116}"(voff[0]), "{v117}"(voff[1]), "{v118}"(voff[2]), "{v119}"(voff[3]),
@@ -372,13 +399,16 @@ def main():
         ABLATE = int(sys.argv[sys.argv.index("--ablate") + 1])
         path = sys.argv[sys.argv.index("--out") + 1]
     clob = "".join(f', "v{i}"' for i in list(range(64, 112)) + list(range(126, 134)))
-    global DEFF, KSTEPS, NSTEP
+    global DEFF, KSTEPS, NSTEP, MASKED
     text = HEADER
-    for deff in (128, 96):
-        DEFF, KSTEPS, NSTEP = deff, deff // 16, 2 * (deff // 32)
-        for T, mf, cvt in (("__bf16", "v_mfma_f32_32x32x16_bf16", cvt_bf16), ("_Float16", "v_mfma_f32_32x32x16_f16", cvt_f16)):
-            lines = gen_block(mf, cvt)
-            text += "\n" + FUNC % {"T": T, "DEFF": deff, "body": render(lines), "clobbers": clob, "vregion": 3 * TILE}
+    for masked in (False, True):
+        for deff in (128, 96):
+            DEFF, KSTEPS, NSTEP, MASKED = deff, deff // 16, 2 * (deff // 32), masked
+            for T, mf, cvt in (("__bf16", "v_mfma_f32_32x32x16_bf16", cvt_bf16), ("_Float16", "v_mfma_f32_32x32x16_f16", cvt_f16)):
+                lines = gen_block(mf, cvt)
+                text += "\n" + FUNC % {"T": T, "DEFF": deff, "MASKED": "true" if masked else "false", "body": render(lines),
+                                       "clobbers": clob + (', "v139"' if masked else ""), "vregion": 3 * TILE,
+                                       "maskout": ', "+{v137}"(ra), "+{v138}"(rb)' if masked else ""}
     text += "\n}  // namespace fa\n"
     if "--check" in sys.argv:
         sys.exit(0 if os.path.exists(path) and open(path).read() == text else 1)
