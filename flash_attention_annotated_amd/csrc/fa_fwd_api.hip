@@ -247,8 +247,10 @@ int effective_variant(const fa_fwd_params *p) {
             //   d128 causal s512/1024:      230/345     -> 293/364      TFLOP/s (8 waves x 32 rows)
             const bool causal_like = p->is_causal || (p->window_size_right == 0 && p->window_size_left < 0);
             const int tile = head_dim_tile(p->d);
+            // (round 2: at head-dim tile 128 the generated loop applies the causal mask itself -- the diagonal tiles no longer
+            //  run the generic half-step -- and the 256-row kernel wins from seqlen 512 on: causal s512 / s1024 308 / 379
+            //  (8 waves x 32 rows) -> 319 / 485 TFLOP/s; the d64 kernel has no generated loop yet and keeps the rule)
             if (tile == 64 && ((causal_like && p->seqlen_k <= 2048) || p->seqlen_k <= 512)) variant = 2;
-            else if (tile == 128 && causal_like && p->seqlen_k <= 1024) variant = 1;
         }
     }
     return variant;
