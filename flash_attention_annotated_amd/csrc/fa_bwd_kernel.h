@@ -27,6 +27,7 @@
 
 #include "fa_fwd_kernel.h"
 #include "fa_fwd_kernel_w64.h"  // Mfma<T>: inline-asm MFMAs with explicit register classes
+#include "fa_bwd_loop_gen.h"    // BwdLoop128<T>: the generated dK / dV tile loop (tools/gen_bwd_loop.py)
 
 namespace fa {
 
@@ -63,6 +64,10 @@ __device__ __forceinline__ void drain_acc(f32x16 (&a)[N]) {
     else asm volatile("s_nop 15\n\ts_nop 7" : "+a"(a[0]), "+a"(a[1]), "+a"(a[2]), "+a"(a[3]), "+a"(a[4]), "+a"(a[5]),
                       "+a"(a[6]), "+a"(a[7]));
 }
+
+#ifndef FA_BWD_ABLATE
+#define FA_BWD_ABLATE 0  // developer-only: 1 = no generated asm block in bwd_dkdv_kernel
+#endif
 
 struct BParams {
     const void *q, *k, *v, *o, *dout;
@@ -437,6 +442,58 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_kernel(const BParams p) {
 
     for (int it = 0; it < total_it; ++it) {
         const int cur = it & 1;
+        // The bulk of the sweep at head dim 128: runs of tiles of one head with nothing to mask for this wave's keys go through
+        // the generated asm block (fa_bwd_loop_gen.h; same LDS layout and barrier protocol, so the four waves choose
+        // independently).  The tile behind a run must belong to the same head (the block prefetches it through the head's
+        // buffer descriptors); the run's tiles lie fully inside the sequence.
+        if constexpr (D == 128 && NB == 1 && !SOFTCAP && !DROPOUT && DMA && !(FA_BWD_ABLATE & 1)) {
+            const int row0 = tile_row0(it);
+            const int left = num_m - it % num_m;  // tiles of this head from `it` on
+            int hi_row = sq - BM;
+            if (p.window_left >= 0) hi_row = min(hi_row, key_w0 - (BM - 1) - shift + p.window_left);
+            int plain = row0 <= hi_row ? (hi_row - row0) / BM + 1 : 0;
+            if (key_w0 + WKEYS > sk) plain = 0;
+            if (p.window_right >= 0 && key_w0 + WKEYS - 1 > row0 + shift + p.window_right) plain = 0;
+            const int count = min(plain, left - 1);
+            const bool addr32 = (int64_t)sq * p.q_row_stride < (1ll << 30) && (int64_t)sq * p.do_row_stride < (1ll << 30);
+            if (count >= 2 && !p.alibi && addr32) {
+                const int head = tile_head(it);
+                auto make_desc = [&](const void *base, uint32_t bytes) {
+                    const uint64_t b = (uint64_t)(uintptr_t)base;
+                    u32x4 dsc;
+                    dsc[0] = (uint32_t)b;
+                    dsc[1] = (uint32_t)(b >> 32) & 0xffffu;  // stride 0: raw buffer
+                    dsc[2] = bytes;                          // past it: zeros
+                    dsc[3] = 0x00020000u;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) dsc[i] = __builtin_amdgcn_readfirstlane(dsc[i]);
+                    return dsc;
+                };
+                const T *qp = (const T *)p.q + sq_.q_base + (int64_t)head * p.q_head_stride;
+                const T *gp = (const T *)p.dout + sq_.do_base + (int64_t)head * p.do_head_stride;
+                const u32x4 qdesc = make_desc(qp, (uint32_t)(((int64_t)(sq - 1) * p.q_row_stride + min(p.d, D)) * 2));
+                const u32x4 gdesc = make_desc(gp, (uint32_t)(((int64_t)(sq - 1) * p.do_row_stride + min(p.d, D)) * 2));
+                const bool odd = (wave & 1) != 0;  // waves 0, 2 stage the LSE row of the next tile, waves 1, 3 its D row
+                const float *sp = odd ? p.dsum + sq_.dsum_base + (int64_t)head * sq_.dsum_hs
+                                      : p.lse + sq_.stat_base + (int64_t)head * sq_.lse_hs;
+                const u32x4 sdesc = make_desc(sp, (uint32_t)sq * 4u);
+                uint32_t qoffb[LD_PER_THREAD], goffb[LD_PER_THREAD];
+#pragma unroll
+                for (int i = 0; i < LD_PER_THREAD; ++i) {
+                    qoffb[i] = q_off[i] - 1024u * i;  // (the instruction offset that steps the LDS target also enters the source)
+                    goffb[i] = g_off[i] - 1024u * i;
+                }
+                const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
+                const uint32_t stat0 = lds0 + 4 * TILE_BYTES;
+                BwdLoop128<T>::run(dk_acc, dv_acc, kf[0], vf[0], (uint32_t)kbase, (uint32_t)vbase, qoffb, goffb,
+                                   stat0 + 16 * hh, (uint32_t)lane * 4u, stat0 + (odd ? 2 * BM * 4 : 0) + lane * 4, p.scale_log2,
+                                   odd ? 1.f : LOG2E, qdesc, gdesc, sdesc, (uint32_t)((row0 + BM) * q_rs * 2),
+                                   (uint32_t)((row0 + BM) * g_rs * 2), (uint32_t)((row0 + BM) * 4), (uint32_t)(BM * q_rs * 2),
+                                   (uint32_t)(BM * g_rs * 2), lds0, lds_wave, cur, count);
+                it += count - 1;  // tile it + count is in LDS, its barrier passed
+                continue;
+            }
+        }
         const bool has_next = it + 1 < total_it;
         if (has_next) load_tile(it + 1, cur ^ 1);  // (buffer cur^1 was last read before the previous barrier)
 

@@ -50,5 +50,13 @@ def test_no_unpadded_mfma_or_trans_hazards(tmp_path, unit):
         elif "fwd_kernel" in name:
             softcap = re.search(r"Li\d+ELi\d+ELb1", name) is not None
             assert len(inside) <= (1 if softcap else 0), (name, inside)
+        elif "bwd_dkdv_kernel" in name and ".Lfb_exit_" in "\n".join(lines):
+            # head dim 128, plain: the bulk of the sweep is the generated block (tools/gen_bwd_loop.py), whose fixed register map
+            # leaves the C++ tile path (boundary tiles only) a few spilled loop invariants; none inside the block, 64 MFMAs per
+            # unrolled tile
+            body = "\n".join(lines)
+            blk = body[body.index(".Lfb_t1_"):body.rindex(".Lfb_exit_")]
+            assert "scratch_" not in blk and blk.count("v_mfma") == 128, name
+            assert any_scratch <= 24, (name, any_scratch)
         elif "bwd_" in name and "Li256E" not in name:
             assert any_scratch == 0, (name, any_scratch)
