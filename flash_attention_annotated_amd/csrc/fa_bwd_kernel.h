@@ -28,6 +28,7 @@
 #include "fa_fwd_kernel.h"
 #include "fa_fwd_kernel_w64.h"  // Mfma<T>: inline-asm MFMAs with explicit register classes
 #include "fa_bwd_loop_gen.h"    // BwdLoop128<T>: the generated dK / dV tile loop (tools/gen_bwd_loop.py)
+#include "fa_bwd_dq_loop_gen.h" // BwdDqLoop128<T>: the generated dQ tile loop (tools/gen_bwd_dq_loop.py)
 
 namespace fa {
 
@@ -682,6 +683,8 @@ constexpr int smem_bytes_dkdv() {
     return tiles > o ? tiles : o;
 }
 
+template <int D> constexpr int dq_nbuf() { return D == 128 ? 3 : 2; }  // K / V LDS slots of bwd_dq_kernel
+
 // ------------------------------------------------------------------------------------------------------------------
 // dQ.  NB = 32-row query blocks per wave (K / V / K^T fragments from LDS feed NB MFMAs each).
 // ------------------------------------------------------------------------------------------------------------------
@@ -700,7 +703,10 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_kernel(const BParams p) {
     constexpr int O_ROW_BYTES = D * 2 + 16;
     constexpr float LOG2E = 1.4426950408889634f;
 
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // [K0 | K1 | V0 | V1]
+    // [K0 .. K(NBUF-1) | V0 .. V(NBUF-1)]: two slots, three at head dim 128 (the generated block reads a tile's K one barrier
+    // longer than the C++ path: see tools/gen_bwd_dq_loop.py)
+    constexpr int NBUF = dq_nbuf<D>();
+    extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -800,7 +806,7 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_kernel(const BParams p) {
             const T *kt = kp + (int64_t)k0 * p.k_row_stride, *vt = vp + (int64_t)k0 * p.v_row_stride;  // wave-uniform
             if (k0 + BLOCK_N <= sk) {
                 lds_dma<LD_PER_THREAD>(lds_wave + buf * TILE_BYTES, kt, k_off);
-                lds_dma<LD_PER_THREAD>(lds_wave + (2 + buf) * TILE_BYTES, vt, v_off);
+                lds_dma<LD_PER_THREAD>(lds_wave + (NBUF + buf) * TILE_BYTES, vt, v_off);
             } else {
                 uint32_t ko[LD_PER_THREAD], vo[LD_PER_THREAD];
 #pragma unroll
@@ -810,7 +816,7 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_kernel(const BParams p) {
                     vo[i] = (uint32_t)(rel * v_rs + dma_col[i]) * 2u;
                 }
                 lds_dma<LD_PER_THREAD>(lds_wave + buf * TILE_BYTES, kt, ko);
-                lds_dma<LD_PER_THREAD>(lds_wave + (2 + buf) * TILE_BYTES, vt, vo);
+                lds_dma<LD_PER_THREAD>(lds_wave + (NBUF + buf) * TILE_BYTES, vt, vo);
             }
         } else {
 #pragma unroll
@@ -831,7 +837,7 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_kernel(const BParams p) {
                 const int c = tid + i * NT;
                 const int off = lds_off<D>(c / CH_PER_ROW, c % CH_PER_ROW);
                 *(u32x4 *)(smem + buf * TILE_BYTES + off) = kreg[i];
-                *(u32x4 *)(smem + (2 + buf) * TILE_BYTES + off) = vreg[i];
+                *(u32x4 *)(smem + (NBUF + buf) * TILE_BYTES + off) = vreg[i];
             }
         }
     };
@@ -844,9 +850,53 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_kernel(const BParams p) {
     tile_barrier<0>();
 
     for (int n = n_min; n < n_max; ++n) {
-        const int cur = (n - n_min) & 1;
+        const int cur = (n - n_min) % NBUF;
+        const int nxt = (cur + 1) % NBUF;
+        // The bulk of the sweep at head dim 128: runs of tiles with nothing to mask for this wave's rows go through the
+        // generated asm block (fa_bwd_dq_loop_gen.h; same barrier / LDS-DMA protocol, so the four waves choose independently).
+        if constexpr (D == 128 && NB == 2 && !SOFTCAP && !DROPOUT && DMA && !(FA_BWD_ABLATE & 2)) {
+            int n_hi = sk / BLOCK_N - 1;  // last tile fully inside the keys
+            if (p.window_right >= 0) {
+                const int lim = wrow + shift + p.window_right - (BLOCK_N - 1);  // first key of the tile <= lim
+                n_hi = min(n_hi, lim >= 0 ? lim / BLOCK_N : -1);
+            }
+            int n_lo = 0;
+            if (p.window_left >= 0) {
+                const int lo = wrow + WROWS - 1 + shift - p.window_left;        // first key of the tile >= lo
+                n_lo = lo > 0 ? (lo + BLOCK_N - 1) / BLOCK_N : 0;
+            }
+            const int count = (n >= n_lo && n <= n_hi) ? min(n_hi, n_max - 1) - n + 1 : 0;
+            const bool addr32 = (int64_t)sk * p.k_row_stride < (1ll << 30) && (int64_t)sk * p.v_row_stride < (1ll << 30);
+            if (count >= 2 && wave_active && !p.alibi && addr32) {
+                auto make_desc = [&](const T *base, int64_t rs64) {
+                    const uint64_t b = (uint64_t)(uintptr_t)base;
+                    u32x4 dsc;
+                    dsc[0] = (uint32_t)b;
+                    dsc[1] = (uint32_t)(b >> 32) & 0xffffu;                            // stride 0: raw buffer
+                    dsc[2] = (uint32_t)(((int64_t)(sk - 1) * rs64 + min(p.d, D)) * 2);  // past the last valid row: zeros
+                    dsc[3] = 0x00020000u;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) dsc[i] = __builtin_amdgcn_readfirstlane(dsc[i]);
+                    return dsc;
+                };
+                const u32x4 kdesc = make_desc(kp, p.k_row_stride), vdesc = make_desc(vp, p.v_row_stride);
+                uint32_t koffb[LD_PER_THREAD], voffb[LD_PER_THREAD];
+#pragma unroll
+                for (int i = 0; i < LD_PER_THREAD; ++i) {
+                    koffb[i] = k_off[i] - 1024u * i;  // (the instruction offset that steps the LDS target also enters the source)
+                    voffb[i] = v_off[i] - 1024u * i;
+                }
+                const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
+                BwdDqLoop128<T>::run(dq_acc, qf[0], qf[1], gf[0], gf[1], lse2[0], lse2[1], dsum[0], dsum[1], (uint32_t)kbase,
+                                     (uint32_t)vbase, koffb, voffb, p.scale_log2, kdesc, vdesc,
+                                     (uint32_t)((n + 1) * BLOCK_N * k_rs * 2), (uint32_t)((n + 1) * BLOCK_N * v_rs * 2),
+                                     (uint32_t)(BLOCK_N * k_rs * 2), (uint32_t)(BLOCK_N * v_rs * 2), lds0, lds_wave, cur, count);
+                n += count - 1;  // tile n + count is in LDS, its barrier passed
+                continue;
+            }
+        }
         const bool has_next = n + 1 < n_max;
-        if (has_next) load_tile(n + 1, cur ^ 1);
+        if (has_next) load_tile(n + 1, nxt);
 
         const int k0 = n * BLOCK_N;
         bool skip = !wave_active;
@@ -859,7 +909,7 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_kernel(const BParams p) {
 
         if (!skip) {
             const char *kbuf = smem + cur * TILE_BYTES;
-            const char *vbuf = smem + (2 + cur) * TILE_BYTES;
+            const char *vbuf = smem + (NBUF + cur) * TILE_BYTES;
             // two 32-key halves, one after the other (keeps the live score accumulators at 32 NB registers)
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
@@ -955,11 +1005,14 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_kernel(const BParams p) {
             }
         }
 
-        if (has_next) store_tile(cur ^ 1);
+        if (has_next) store_tile(nxt);
         tile_barrier<0>();
     }
 
     // ---- epilogue ---------------------------------------------------------------------------------------------
+    // (a wave leaving the generated block reads its last tile's K^T fragments AFTER the last tile barrier: nobody may
+    //  reuse the LDS before every wave is here)
+    if constexpr (NBUF == 3) __syncthreads();
     drain_acc(dq_acc);  // asm MFMA results -> VALU readers
     T *dqp = (T *)p.dq + sq_.dq_base + (int64_t)head * p.dq_head_stride;
     char *obuf = smem + wave * (32 * O_ROW_BYTES);
@@ -992,7 +1045,7 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_kernel(const BParams p) {
 
 template <int D>
 constexpr int smem_bytes_dq() {
-    constexpr int kv = 4 * BLOCK_N * D * 2;
+    constexpr int kv = 2 * dq_nbuf<D>() * BLOCK_N * D * 2;
     constexpr int o = 4 * 32 * (D * 2 + 16);
     return kv > o ? kv : o;
 }

@@ -132,6 +132,22 @@ def test_local_window_grads(sq, sk, window):
     _check_grads(got, ref, pt, f"window={window}")
 
 
+@pytest.mark.parametrize("window", [(128, 0), (96, 64), (-1, 40), (200, -1)])
+@pytest.mark.parametrize("sq,sk", [(640, 640), (448, 704), (705, 450)])
+def test_local_window_grads_d128(sq, sk, window):
+    """Head dim 128 under sliding windows: the generated dK/dV and dQ blocks take the runs of tiles the window leaves
+    unmasked for each wave (lower AND upper tile limits), the C++ tile path the boundary tiles around them."""
+    fa = _api()
+    torch.manual_seed(3)
+    q = torch.randn(1, sq, 4, 128, dtype=torch.bfloat16)
+    k = torch.randn(1, sk, 2, 128, dtype=torch.bfloat16)
+    v = torch.randn(1, sk, 2, 128, dtype=torch.bfloat16)
+    g = torch.randn(1, sq, 4, 128, dtype=torch.bfloat16)
+    _, got = _hip_grads(fa.flash_attn_func, q, k, v, g, window_size=window)
+    ref, pt = _oracle_grads(q, k, v, g, window_size=window)
+    _check_grads(got, ref, pt, f"window={window} {sq}x{sk}")
+
+
 def test_alibi_and_softcap_grads():
     fa = _api()
     torch.manual_seed(3)

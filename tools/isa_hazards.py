@@ -48,6 +48,9 @@ def scan(path, required=REQUIRED):
         if not l or l.startswith(';') or l.startswith('.') or l.endswith(':'):
             continue
         op = l.split()[0]
+        if op == 's_branch':   # unconditional: the next line is not this one's successor
+            window, mfma_out, last_trans = [], [], None
+            continue
         # gfx940+ trans forwarding: a non-transcendental VALU may not read a transcendental's result in the very
         # next instruction (1 wait state); hipcc pads this only for instructions it scheduled itself
         if last_trans is not None and op.startswith('v_') and not op.startswith(TRANS):
