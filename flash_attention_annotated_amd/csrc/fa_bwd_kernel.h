@@ -27,7 +27,11 @@
 
 #include "fa_fwd_kernel.h"
 #include "fa_fwd_kernel_w64.h"  // Mfma<T>: inline-asm MFMAs with explicit register classes
+#ifdef FA_BWD_LOOP_HEADER          // developer-only: an ablated build of the generated loop (tools/gen_bwd_loop.py --ablate)
+#include FA_BWD_LOOP_HEADER
+#else
 #include "fa_bwd_loop_gen.h"    // BwdLoop128<T>: the generated dK / dV tile loop (tools/gen_bwd_loop.py)
+#endif
 #include "fa_bwd_dq_loop_gen.h" // BwdDqLoop128<T>: the generated dQ tile loop (tools/gen_bwd_dq_loop.py)
 
 namespace fa {

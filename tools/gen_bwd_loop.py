@@ -26,6 +26,8 @@ STAT = 4 * TILE             # lse_s[2][64] then dsum_s[2][64] (fp32)
 KSTEPS = D // 16
 NSTEP = 2 * (D // 32)
 LD = 4
+# developer-only timing ablations (results are WRONG when non-zero; `--ablate N --out path`, never committed): 8 no pointwise VALU
+ABLATE = 0
 
 # ---- arch VGPRs ----
 S0, DP0, S1, DP1 = 0, 16, 32, 48
@@ -141,7 +143,8 @@ class Slots:
             elif isinstance(it, tuple):
                 self.E.wait_for(it[1])
             else:
-                self.E.e(it)
+                if not (ABLATE & 8):
+                    self.E.e(it)
                 n += 1
 
 
@@ -342,8 +345,12 @@ def render(lines):
 
 
 def main():
+    global ABLATE
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     path = os.path.join(root, "flash_attention_annotated_amd", "csrc", "fa_bwd_loop_gen.h")
+    if "--ablate" in sys.argv:
+        ABLATE = int(sys.argv[sys.argv.index("--ablate") + 1])
+        path = sys.argv[sys.argv.index("--out") + 1]
     inputs = set(range(192, 200)) | {200, 202, 203, 208, 209}
     clob = "".join(f', "v{i}"' for i in range(NVGPR) if i not in inputs)
     text = HEADER
