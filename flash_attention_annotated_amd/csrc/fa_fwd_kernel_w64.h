@@ -359,11 +359,16 @@ __device__ unsigned long long fa_timing_buf[32 * 4096];
 // wall clock at the first and last stamp (slots 62, 63), into spare LDS; copied to fa_cycle_buf[workgroup][wave][64] at
 // the end.  The stamp drains lgkmcnt (s_memtime returns through it), i.e. it perturbs the LDS prefetch by ~100 cycles.
 #ifdef FA_CYCLES
+#ifndef FA_CYCLES_WG0
+#define FA_CYCLES_WG0 0   // first of the 256 workgroups whose stamps are kept (0: the launch's first round, cold caches)
+#endif
 __device__ unsigned long long fa_cycle_buf[256 * 4 * 64];
 #define FA_C() do { if (cyc_n < 60) { unsigned long long *cb_ = (unsigned long long *)(smem + 6 * BLOCK_N * D * 2 + 1024) + (threadIdx.x >> 6) * 64; \
         if (cyc_n == 0) cb_[62] = __builtin_amdgcn_s_memrealtime(); cb_[cyc_n++] = __builtin_amdgcn_s_memtime(); cb_[63] = __builtin_amdgcn_s_memrealtime(); cb_[61] = cyc_n; } } while (0)
+#define FA_STAMP(k) (((unsigned long long *)(smem + 6 * BLOCK_N * D * 2 + 1024))[(threadIdx.x >> 6) * 64 + (k)] = __builtin_amdgcn_s_memrealtime())
 #else
 #define FA_C()
+#define FA_STAMP(k)
 #endif
 
 // DEFF (head-dim tile 128 only): 96 when the head dim is <= 96 -- the generated loop then skips the k-steps and O blocks
@@ -715,6 +720,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
         if (n_min + 1 < n_max) load_v(n_min + 1, 1);
     }
     FA_T(1);
+    FA_STAMP(48);  // Q loads and the first K/V tiles requested
     {
         const u32x4 z4 = {0, 0, 0, 0};
 #pragma unroll
@@ -731,7 +737,9 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
         asm volatile("; pin Q" : "+a"(qb[ks]));
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): Q has landed; nothing compiler-visible stays pending
+    FA_STAMP(49);
     tile_barrier<0>();                   // first tiles landed (asm LDS-DMA) and visible to every wave
+    FA_STAMP(50);
     FA_T(2);
     int in_flight = 0;                   // LDS-DMA pieces this wave issued at the top of the current tile
 
@@ -1148,7 +1156,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     // 8), i.e. behind the same L2.  Its Q rows are a cold, badly coalesced gather (~4 us: tools/wg_phases.py); touching one
     // dword of each of their cache lines here, with the whole epilogue (~3 us) in front of the end of this workgroup, turns
     // that into L2 hits.  The data lands in a 1 KiB dump area of LDS; dense batches only (no cu_seqlens lookups here).
-#ifndef FA_CYCLES
+    FA_STAMP(51);  // key sweep done
     if (!p.cu_seqlens_q && !p.seqused_q && p.num_splits <= 1 && p.q_row_stride < (1 << 20)) {
         const int wg2 = blockIdx.x + p.num_cus;
         const int slot2 = wg2 >> 3;
@@ -1168,7 +1176,6 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
             for (int line = 0; line < (D * 2) / 128; ++line) lds_dma_touch(dump, q2, off2 + line * 128);
         }
     }
-#endif
     drain_all();        // asm MFMA results -> VALU readers
     // lane constants are rebuilt from the lane id here: the ones computed in front of the main loop were spilled to
     // scratch by then, and every reload is a separately awaited memory round trip (tools/wg_phases.py: 3.3 us epilogue)
@@ -1200,6 +1207,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
             }
     }
     __syncthreads();
+    FA_STAMP(52);  // O normalised and in LDS
     if (wave_active) {
         const char *obuf = smem + wave * (64 * O_ROW_BYTES);
         // (LDS reads outside the predicate: all of them are issued before the first store; inside it each read is
@@ -1222,8 +1230,8 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
 #ifdef FA_CYCLES
     ((unsigned long long *)(smem + 6 * BLOCK_N * D * 2 + 1024))[(threadIdx.x >> 6) * 64 + 47] = __builtin_amdgcn_s_memrealtime();
     __syncthreads();
-    if (blockIdx.x < 256)
-        fa_cycle_buf[blockIdx.x * 256 + threadIdx.x] = ((unsigned long long *)(smem + 6 * BLOCK_N * D * 2 + 1024))[threadIdx.x];
+    if (blockIdx.x >= FA_CYCLES_WG0 && blockIdx.x < FA_CYCLES_WG0 + 256)
+        fa_cycle_buf[(blockIdx.x - FA_CYCLES_WG0) * 256 + threadIdx.x] = ((unsigned long long *)(smem + 6 * BLOCK_N * D * 2 + 1024))[threadIdx.x];
 #endif
 #ifdef FA_TIMING
     FA_T(6);
@@ -1240,7 +1248,7 @@ constexpr int smem_bytes_w64() {
     constexpr int kv = 6 * BLOCK_N * D * 2;  // the K/V rings; the O staging of the epilogue (4 x 64 x (2 D + 16)) fits inside
     static_assert(kv >= 4 * 64 * (D * 2 + 16), "O staging must fit the K/V rings");
 #if defined(FA_CYCLES)
-    return kv + 1024 + 2048;  // + cycle stamps (the Q prefetch dump area is off in this build)
+    return kv + 1024 + 2048;  // + dump area of the Q prefetch + cycle stamps
 #elif defined(FA_TIMING)
     return kv + 1024 + 256;  // + dump area of the Q prefetch + time stamps
 #else

@@ -31,6 +31,12 @@ if buf[0, 0, 44] > 0:  # generated asm loop (head-dim tile 128): one stamp pair 
     t0, t1, t2, t3 = (buf[:, :, k].astype(np.float64) * 0.01 for k in (46, 42, 43, 47))  # us
     print(f"workgroup timeline (wave medians, us): entry -> block {np.median(t1 - t0):.2f} | asm block {np.median(t2 - t1):.2f} | "
           f"block -> O stores issued {np.median(t3 - t2):.2f} | total {np.median(t3 - t0):.2f}")
+    if buf[0, 0, 48] > 0:  # finer stamps (100 MHz wall clock)
+        e = {k: buf[:, :, k].astype(np.float64) * 0.01 for k in (46, 48, 49, 50, 42, 43, 51, 52, 47)}
+        seg = [("entry -> Q loads + first K/V tiles requested", 46, 48), ("-> Q landed (vmcnt 0)", 48, 49), ("-> first tile barrier", 49, 50),
+               ("-> asm block entry (first scores, softmax A(0))", 50, 42), ("asm block", 42, 43), ("-> key sweep done", 43, 51),
+               ("-> O normalised, in LDS", 51, 52), ("-> O stores issued", 52, 47)]
+        print("  " + " | ".join(f"{n} {np.median(e[b_] - e[a_]):.2f}" for n, a_, b_ in seg))
 n = int(buf[0, 0, 61])
 if n < 8:
     sys.exit(0)
