@@ -306,6 +306,12 @@ __device__ __forceinline__ void lds_dma1(uint32_t lds, const void *base, uint32_
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "s"(base), "s"(lds), "v"(off) : "memory");
 }
+// one 1-KiB piece through a raw buffer descriptor: lanes whose offset is past num_records land as zeros
+__device__ __forceinline__ void lds_dma_buf1(uint32_t lds, u32x4 desc, uint32_t off) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %1, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(desc), "s"(lds), "v"(off) : "memory");
+}
 // 64 lanes x 4 B (touches one cache line per lane): used to pull lines into the L2 ahead of time, the LDS copy is a dump
 __device__ __forceinline__ void lds_dma_touch(uint32_t lds, const void *base, uint32_t off) {
     uint32_t keep;
@@ -366,9 +372,14 @@ __device__ unsigned long long fa_cycle_buf[256 * 4 * 64];
 #define FA_C() do { if (cyc_n < 60) { unsigned long long *cb_ = (unsigned long long *)(smem + 6 * BLOCK_N * D * 2 + 1024) + (threadIdx.x >> 6) * 64; \
         if (cyc_n == 0) cb_[62] = __builtin_amdgcn_s_memrealtime(); cb_[cyc_n++] = __builtin_amdgcn_s_memtime(); cb_[63] = __builtin_amdgcn_s_memrealtime(); cb_[61] = cyc_n; } } while (0)
 #define FA_STAMP(k) (((unsigned long long *)(smem + 6 * BLOCK_N * D * 2 + 1024))[(threadIdx.x >> 6) * 64 + (k)] = __builtin_amdgcn_s_memrealtime())
+// (the stamp area lies inside the Q staging image: stamps taken before the Q fragments are in registers wait in scalars)
+#define FA_STAMP_VAR(k) const unsigned long long fa_st_##k = __builtin_amdgcn_s_memrealtime()
+#define FA_STAMP_FLUSH(k) (((unsigned long long *)(smem + 6 * BLOCK_N * D * 2 + 1024))[(threadIdx.x >> 6) * 64 + (k)] = fa_st_##k)
 #else
 #define FA_C()
 #define FA_STAMP(k)
+#define FA_STAMP_VAR(k)
+#define FA_STAMP_FLUSH(k)
 #endif
 
 // DEFF (head-dim tile 128 only): 96 when the head dim is <= 96 -- the generated loop then skips the k-steps and O blocks
@@ -479,27 +490,9 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     if (wrow >= sq || n_min >= n_max) jend = 0;
     jend = __builtin_amdgcn_readfirstlane(jend);
 
-#ifdef FA_CYCLES
-    ((unsigned long long *)(smem + 6 * BLOCK_N * D * 2 + 1024))[(threadIdx.x >> 6) * 64 + 46] = __builtin_amdgcn_s_memrealtime();
-#endif
-    // ---- Q fragments (B operand of S^T = K.Q^T) -------------------------------------------------------
-    // Branch-free: rows past the end are clamped to the last one and head-dim chunks past d to chunk 0, then zeroed by
-    // selects.  The loads are a lane-per-row gather (32 B of each 128-B line per instruction): ~4 us until they are
-    // back at D = 128 (tools/wg_phases.py), the largest single piece of the per-workgroup fixed cost.
+    FA_STAMP_VAR(46);
+    // ---- Q fragments (B operand of S^T = K.Q^T): fetched in the prologue below, behind the first K tile ----------
     u32x4 qa[KSTEPS], qb[KSTEPS];
-    {
-        const T *qra = qp + (int64_t)min(row_a, sq - 1) * p.q_row_stride;
-        const T *qrb = qp + (int64_t)min(row_b, sq - 1) * p.q_row_stride;
-#pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) {
-            const int d0 = ks * 16 + hh * 8;
-            const int dc = d0 < p.d ? d0 : 0;
-            qa[ks] = *(const u32x4 *)(qra + dc);
-            qb[ks] = *(const u32x4 *)(qrb + dc);
-        }
-    }
-    // (the zeroing selects and the AGPR pin wait for the loads: they sit behind the issue of the first K/V tiles below,
-    //  so that the two HBM round trips overlap)
 
     f32x16 oa[DBLOCKS], ob[DBLOCKS];
     {
@@ -581,6 +574,23 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
             } else {
                 Mfma<T>::s_acc_pad(sa, kf, qa[ks]);
                 Mfma<T>::s_acc_pad(sb, kf, qb[ks]);
+            }
+        }
+    };
+    // the same for the very first scores: all K fragments requested up front (nothing else hides the LDS latency there)
+    auto qk_half_first = [&](int kbuf, int kh, f32x16 &sa, f32x16 &sb) {
+        const char *base = smem + kbuf * TILE_BYTES + kh * (32 * ROWB);
+        u32x4 kf[KSTEPS];
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) kf[ks] = *(const u32x4 *)(base + (kbase ^ (32 * ks)));
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            if (ks == 0) {
+                Mfma<T>::s_first_pad(sa, kf[ks], qa[ks]);
+                Mfma<T>::s_first_pad(sb, kf[ks], qb[ks]);
+            } else {
+                Mfma<T>::s_acc_pad(sa, kf[ks], qa[ks]);
+                Mfma<T>::s_acc_pad(sb, kf[ks], qb[ks]);
             }
         }
     };
@@ -711,23 +721,53 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
         drain_mfma(o);  // VALU / accvgpr writes -> next MFMA reading them as SrcC
     };
 
-    // ---- prologue: K tiles n_min and n_min+1, V tile n_min; first scores; softmax of A(0) -------------
+    // ---- prologue: K tiles n_min and n_min+1, V tile n_min; Q; first scores; softmax of A(0) ----------------------
+    // Q: this wave's 64 rows by LDS-DMA (CH_PER_ROW coalesced 1-KiB pieces) into its own 64-row tile image behind the K/V
+    // rings -- same swizzle as a K tile, so the fragment reads are the K fragment reads -- through a raw buffer descriptor:
+    // rows past the end of q and head-dim chunks past d land as zeros.  (Round 1 gathered the fragments lane-per-row from
+    // global memory, 32 B of each 128-B line per instruction: 2.4 us until the requests were even issued.)
+    if (n_min < n_max) load_k(n_min, 0);
+    {
+        const int rows_here = min(sq - wrow, 64);  // <= 0: nothing of this wave's rows exists
+        const uint64_t qb_ = (uint64_t)(uintptr_t)(qp + (int64_t)wrow * p.q_row_stride);
+        u32x4 qdesc;
+        qdesc[0] = (uint32_t)qb_;
+        qdesc[1] = (uint32_t)(qb_ >> 32) & 0xffffu;  // stride 0: raw buffer
+        qdesc[2] = rows_here > 0 ? (uint32_t)(((int64_t)(rows_here - 1) * p.q_row_stride + min(p.d, D)) * 2) : 0u;
+        qdesc[3] = 0x00020000u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) qdesc[i] = __builtin_amdgcn_readfirstlane(qdesc[i]);
+        const uint32_t q_img = lds0 + 6 * TILE_BYTES + wave * TILE_BYTES;
+        const int q_rs = (int)p.q_row_stride;
+#pragma unroll
+        for (int i = 0; i < CH_PER_ROW; ++i) {
+            const int slot = i * 64 + lane;
+            const int row = slot / CH_PER_ROW;
+            int ch;  // inverse of lds_off<D>
+            if constexpr (D == 64) ch = (slot % CH_PER_ROW) ^ ((((row >> 1) & 1) << 2) | ((row >> 2) & 3));
+            else ch = (slot % CH_PER_ROW) ^ (((row & 3) << 2) | ((row >> 2) & 3));
+            const uint32_t off = ch * 8 < p.d ? (uint32_t)(row * q_rs + ch * 8) * 2u : 0x7ffffff0u;
+            lds_dma_buf1(q_img + i * 1024, qdesc, off);
+        }
+    }
     if (n_min < n_max) {
-        load_k(n_min, 0);
         load_v(n_min, 0);
         load_k(n_min + 1, 1);
         if (n_min + 2 <= n_max) load_k(n_min + 2, 2);
         if (n_min + 1 < n_max) load_v(n_min + 1, 1);
     }
     FA_T(1);
-    FA_STAMP(48);  // Q loads and the first K/V tiles requested
+    FA_STAMP_VAR(48);  // Q and the first K/V tiles requested
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    FA_STAMP_VAR(49);
+    tile_barrier<0>();                   // first tiles landed (asm LDS-DMA) and visible to every wave
+    FA_STAMP_VAR(50);
     {
-        const u32x4 z4 = {0, 0, 0, 0};
+        const char *qimg = smem + 6 * TILE_BYTES + wave * TILE_BYTES;
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
-            const bool in_d = ks * 16 + hh * 8 < p.d;
-            qa[ks] = (in_d && row_a < sq) ? qa[ks] : z4;
-            qb[ks] = (in_d && row_b < sq) ? qb[ks] : z4;
+            qa[ks] = *(const u32x4 *)(qimg + (kbase ^ (32 * ks)));
+            qb[ks] = *(const u32x4 *)(qimg + (kbase ^ (32 * ks)) + 32 * ROWB);
         }
     }
     // Q is only ever an MFMA operand: pin it into the AGPR half of the register file (born there, stays there)
@@ -736,10 +776,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
         asm volatile("; pin Q" : "+a"(qa[ks]));
         asm volatile("; pin Q" : "+a"(qb[ks]));
     }
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): Q has landed; nothing compiler-visible stays pending
-    FA_STAMP(49);
-    tile_barrier<0>();                   // first tiles landed (asm LDS-DMA) and visible to every wave
-    FA_STAMP(50);
+    FA_STAMP_FLUSH(46); FA_STAMP_FLUSH(48); FA_STAMP_FLUSH(49); FA_STAMP_FLUSH(50);
     FA_T(2);
     int in_flight = 0;                   // LDS-DMA pieces this wave issued at the top of the current tile
 
@@ -754,7 +791,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     float alpha_a = 1.f, alpha_b = 1.f;
     bool moved_a = false, moved_b = false;
     if (jend > 0) {
-        qk_half(0, 1, sa, sbx);  // half-step 0 = second half of K tile n_min
+        qk_half_first(0, 1, sa, sbx);  // half-step 0 = second half of K tile n_min
         drain_scores(sa, sbx);
         prep_scores(0, sa, sbx);
         softmax(sa, pax, m_a, l_a, alpha_a, moved_a);
@@ -1206,7 +1243,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
                 *(u32x2 *)(obuf + (32 + r_e) * O_ROW_BYTES + col) = wb;
             }
     }
-    __syncthreads();
+    // (no workgroup barrier: a wave reads back only its own 64 staged rows, and LDS operations of one wave are in order)
     FA_STAMP(52);  // O normalised and in LDS
     if (wave_active) {
         const char *obuf = smem + wave * (64 * O_ROW_BYTES);
@@ -1247,13 +1284,9 @@ template <int D>
 constexpr int smem_bytes_w64() {
     constexpr int kv = 6 * BLOCK_N * D * 2;  // the K/V rings; the O staging of the epilogue (4 x 64 x (2 D + 16)) fits inside
     static_assert(kv >= 4 * 64 * (D * 2 + 16), "O staging must fit the K/V rings");
-#if defined(FA_CYCLES)
-    return kv + 1024 + 2048;  // + dump area of the Q prefetch + cycle stamps
-#elif defined(FA_TIMING)
-    return kv + 1024 + 256;  // + dump area of the Q prefetch + time stamps
-#else
-    return kv + 1024;        // + dump area of the Q prefetch (4 waves x 256 B)
-#endif
+    // + the Q staging images (4 waves x 64 rows); once the fragments are in registers the front of that region serves as the
+    // dump area of the successor's L2 prefetch (4 x 256 B) and, in developer builds, holds the time stamps
+    return kv + 4 * BLOCK_N * D * 2;
 }
 
 }  // namespace fa
