@@ -1012,14 +1012,14 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     bool first = true;  // the prologue leaves the pipeline state a fast tile expects: tile 0 may go straight to the fast loop
     while (j < J) {
         // generic until the next tile boundary (at least one half-step, except in front of tile 0: guarantees progress)
-        if (!(first && (tile_ok(0) || (mask_ok && D == 128 && jend > 0)))) {
+        if (!(first && (tile_ok(0) || (mask_ok && jend > 0)))) {
             do {
                 generic_half(j);
                 ++j;
             } while ((j & 1) != 0 && j < J);
         }
         first = false;
-        if ((!tile_ok(j) && !(mask_ok && D == 128 && (j & 1) == 0 && j < jend)) || moved_a || redo_a) continue;
+        if ((!tile_ok(j) && !(mask_ok && (j & 1) == 0 && j < jend)) || moved_a || redo_a) continue;
         {   // B(j) must be safe to exponentiate with its stale max (inside the loop the look-ahead guarantees it)
             float xa, xb;
             rowmax16(sbx, m_b, xa, xb);
@@ -1029,7 +1029,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
         // look-ahead LDS-DMA tiles (K tile n+3, V tile n+2) lie fully inside the sequence.  What it leaves (the last
         // three or so mask-free tiles, whose look-ahead rows have to be clamped) goes through the C++ form below.
         bool tripped = false;
-        if constexpr (D == 128 && !SOFTCAP && !(FA_ABLATE & 32)) {
+        if constexpr (!SOFTCAP && !(FA_ABLATE & 32)) {
             // (the descriptors address bytes with 32 bits: longer sequences stay on the C++ form)
             const bool addr32 = (int64_t)sk * k_rs64 < (1ll << 30) && (int64_t)sk * v_rs64 < (1ll << 30);
             auto run_block = [&](auto masked_c, int count, bool restore_la) {
@@ -1069,7 +1069,8 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
                 unsigned long long *cb_ = (unsigned long long *)(smem + 6 * BLOCK_N * D * 2 + 1024) + (threadIdx.x >> 6) * 64;
                 if (!MASKED) { cb_[40] = __builtin_amdgcn_s_memtime(); cb_[42] = __builtin_amdgcn_s_memrealtime(); cb_[44] = count; }
 #endif
-                FastLoop128<T, DEFF, MASKED>::run(oa, ob, qa, qb, sa, sbx, sby, pax, pay, l_a, l_b, l_a_saved,
+                using Loop = std::conditional_t<D == 128, FastLoop128<T, DEFF, MASKED>, FastLoop64<T, MASKED>>;
+                Loop::run(oa, ob, qa, qb, sa, sbx, sby, pax, pay, l_a, l_b, l_a_saved,
                                                   (m_a == -INFINITY ? 0.f : m_a) * csc, (m_b == -INFINITY ? 0.f : m_b) * csc, m_b,
                                                   (uint32_t)kbase, (uint32_t)vbase, koffb, voffb, csc, THR / csc, LIM, kdesc,
                                                   vdesc, ktile, vtile, (uint32_t)(BLOCK_N * k_rs * 2),
@@ -1109,7 +1110,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
         // tile j/2 (`skip` slots are already behind us); every fast tile issues 2 LD_PER_THREAD LDS-DMA pieces, one per
         // slice of its first half-step
         int skip = (j >> 1) % 3;
-        if constexpr (D != 128 || SOFTCAP || (FA_ABLATE & 32))
+        if constexpr (SOFTCAP || (FA_ABLATE & 32))
         while (!tripped && tile_ok(j)) {
             const int n = n_min + (j >> 1) - skip;  // the tile in ring slot 0 of this turn
             int done = 0;        // half-steps completed in this iteration

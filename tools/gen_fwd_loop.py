@@ -202,16 +202,16 @@ def gen_half(E, slot, KB, uid):
             for i in range(16):
                 E.e(f"v_cmp_gt_i32 vcc, {keyoff(i)}, {v(RA)}")
                 E.e(f"v_cndmask_b32 {v(SA + i)}, {v(SA + i)}, {v(NINF)}, vcc")
-        if MASKED and t < 4:
-            # mask of S_B(j+1), four registers per slice, ahead of the look-ahead max that reads them two slices later
-            for i in range(4 * t, 4 * t + 4):
+        nmask = 4 if NSTEP >= 6 else 2   # slices that carry the mask of S_B(j+1): 4 (or 8) registers each
+        if MASKED and t < nmask:
+            # mask of S_B(j+1), ahead of the look-ahead max that reads each register at least one slice later
+            for i in range((16 // nmask) * t, (16 // nmask) * (t + 1)):
                 E.e(f"v_cmp_gt_i32 vcc, {keyoff(i)}, {v(RB)}")
                 E.e(f"v_cndmask_b32 {v(sb_nxt + i)}, {v(sb_nxt + i)}, {v(NINF)}, vcc")
         prs = pairs_of(t, NSTEP)
         pr = prs[0]
         s0, s1 = SA + 2 * pr, SA + 2 * pr + 1
         last = (t == NSTEP - 1) and not (ABLATE & 2)
-        assert not last or len(prs) == 1
         if not (ABLATE & 8):
             E.e(f"v_fma_f32 {v(T0)}, {v(s0)}, %[csc], -{v(MCA)}")
             E.e(f"v_fma_f32 {v(T1)}, {v(s1)}, %[csc], -{v(MCA)}")
@@ -228,7 +228,8 @@ def gen_half(E, slot, KB, uid):
             E.e(f"v_add_f32 {v(PSA1)}, {v(PSA1)}, {v(T1)}")
             if last:
                 E.e("s_mov_b64 %[bflag], vcc")
-                E.e(f"v_add_f32 {v(TMP)}, {v(PSA0)}, {v(PSA1)}")
+                if len(prs) == 1:
+                    E.e(f"v_add_f32 {v(TMP)}, {v(PSA0)}, {v(PSA1)}")
             for ins in E.cvt(pa_nxt + pr, T0, T1):
                 E.e(ins)
             for pr in prs[1:]:
@@ -241,16 +242,20 @@ def gen_half(E, slot, KB, uid):
                 E.e(f"v_add_f32 {v(PSA1)}, {v(PSA1)}, {v(T1)}")
                 for ins in E.cvt(pa_nxt + pr, T0, T1):
                     E.e(ins)
+            if last and len(prs) > 1:
+                E.e(f"v_add_f32 {v(TMP)}, {v(PSA0)}, {v(PSA1)}")
         # look-ahead max of S_B(j+1) (complete since the end of phase 1), two v_max3 per slice over four slices that end
         # two slices before the guard
-        m0_ = NSTEP - 6
+        nmax = min(4, NSTEP - 2)          # slices that carry the look-ahead max (16 registers: 4 or 8 per slice)
+        m0_ = NSTEP - 2 - nmax
         if MASKED:
             m0_ = max(m0_, 1)  # (registers 4k..4k+3 are masked in slice k: read them from slice k+1 on)
-        if m0_ <= t <= m0_ + 3 and not (ABLATE & 4):
-            i = (t - m0_) * 4
-            first = (t == m0_)
-            E.e(f"v_max3_f32 {v(NXA)}, {v(sb_nxt + i)}, {v(sb_nxt + i + 1)}, {v(MB) if first else v(NXA)}")
-            E.e(f"v_max3_f32 {v(NXB)}, {v(sb_nxt + i + 2)}, {v(sb_nxt + i + 3)}, {v(MB) if first else v(NXB)}")
+        if m0_ <= t < m0_ + nmax and not (ABLATE & 4):
+            per = 16 // nmax
+            for i in range((t - m0_) * per, (t - m0_ + 1) * per, 4):
+                first = (i == 0)
+                E.e(f"v_max3_f32 {v(NXA)}, {v(sb_nxt + i)}, {v(sb_nxt + i + 1)}, {v(MB) if first else v(NXA)}")
+                E.e(f"v_max3_f32 {v(NXB)}, {v(sb_nxt + i + 2)}, {v(sb_nxt + i + 3)}, {v(MB) if first else v(NXB)}")
     if KB == 0:
         E.e("s_add_u32 %[vtile], %[vtile], %[vstep]")
     if MASKED:  # the next half-step's scores start 32 keys further on
@@ -340,16 +345,17 @@ HEADER = '''// GENERATED by tools/gen_fwd_loop.py -- do not edit; regenerate wit
 namespace fa {
 
 template <typename T, int DEFF, bool MASKED = false> struct FastLoop128;
+template <typename T, bool MASKED = false> struct FastLoop64;  // head-dim tile 64 (LDS rows of 128 B, 4 k-steps, 2 O blocks, 2 LDS-DMA pieces per wave)
 // DEFF: head dims contracted / produced (128, or 96: zero padding skipped).  MASKED: the fresh scores S_A(j+1) / S_B(j+1) get
 // the causal / right-window / end-of-sequence mask (key > limit -> -inf; ra / rb = the lane's last visible key minus the key
 // base 64 n_min + 32 (j+1) + 4 (lane >> 5) of the first half-step's NEXT scores): the diagonal and tail tiles of a wave.
 '''
 
-FUNC = '''template <> struct FastLoop128<%(T)s, %(DEFF)d, %(MASKED)s> {
-    static __device__ __forceinline__ void run(f32x16 (&oa)[4], f32x16 (&ob)[4], u32x4 (&qa)[8], u32x4 (&qb)[8], f32x16 &sa,
+FUNC = '''template <> struct %(STRUCT)s {
+    static __device__ __forceinline__ void run(f32x16 (&oa)[%(NDB)d], f32x16 (&ob)[%(NDB)d], u32x4 (&qa)[%(NKS)d], u32x4 (&qb)[%(NKS)d], f32x16 &sa,
                                                f32x16 &sbx, f32x16 &sby, u32x4 (&pax)[2], u32x4 (&pay)[2], float &l_a, float &l_b,
                                                float &l_a_saved, float mca, float mcb, float m_b, uint32_t kbase, uint32_t vbase,
-                                               const uint32_t (&koff)[4], const uint32_t (&voff)[4], float csc, float thr_c,
+                                               const uint32_t (&koff)[%(LD)d], const uint32_t (&voff)[%(LD)d], float csc, float thr_c,
                                                float lim, u32x4 kdesc, u32x4 vdesc, uint32_t ktile, uint32_t vtile,
                                                uint32_t kstep, uint32_t vstep, uint32_t lds0, uint32_t lds_wave, int slot0,
                                                int &count, int &done, uint64_t &redo, int ra = 0, int rb = 0) {
@@ -358,20 +364,14 @@ FUNC = '''template <> struct FastLoop128<%(T)s, %(DEFF)d, %(MASKED)s> {
         const uint32_t lds0v = lds0 + %(vregion)d;
         asm volatile(
 %(body)s
-            : [oa0] "+a"(oa[0]), [oa1] "+a"(oa[1]), [oa2] "+a"(oa[2]), [oa3] "+a"(oa[3]),
-              [ob0] "+a"(ob[0]), [ob1] "+a"(ob[1]), [ob2] "+a"(ob[2]), [ob3] "+a"(ob[3]),
-              [qa0] "+a"(qa[0]), [qa1] "+a"(qa[1]), [qa2] "+a"(qa[2]), [qa3] "+a"(qa[3]),
-              [qa4] "+a"(qa[4]), [qa5] "+a"(qa[5]), [qa6] "+a"(qa[6]), [qa7] "+a"(qa[7]),
-              [qb0] "+a"(qb[0]), [qb1] "+a"(qb[1]), [qb2] "+a"(qb[2]), [qb3] "+a"(qb[3]),
-              [qb4] "+a"(qb[4]), [qb5] "+a"(qb[5]), [qb6] "+a"(qb[6]), [qb7] "+a"(qb[7]),
+            : %(accs)s,
               "+{v[0:15]}"(sa), "+{v[16:31]}"(sbx), "+{v[32:47]}"(sby),
               "+{v[48:51]}"(pax[0]), "+{v[52:55]}"(pax[1]), "+{v[56:59]}"(pay[0]), "+{v[60:63]}"(pay[1]),
               "+{v122}"(l_a), "+{v123}"(l_b), "+{v124}"(l_a_saved),
               [ktile] "+s"(ktile), [vtile] "+s"(vtile),
               [count] "+s"(count), [done] "+s"(done), [redo] "=&s"(redo), [bflag] "=&s"(bflag), [m0save] "=&s"(m0save)%(maskout)s
             : "{v120}"(mca), "{v121}"(mcb), "{v125}"(m_b), "{v136}"(m_b + thr_c), "{v134}"(kbase), "{v135}"(vbase),
-              "{v112}"(koff[0]), "{v113}"(koff[1]), "{v114}"(koff[2]), "{v115}"(koff[3]),
-              "{v116}"(voff[0]), "{v117}"(voff[1]), "{v118}"(voff[2]), "{v119}"(voff[3]),
+              %(offs)s,
               [csc] "s"(csc), [lim] "s"(lim), [kstep] "s"(kstep), [vstep] "s"(vstep),
               [kdesc] "s"(kdesc), [vdesc] "s"(vdesc),
               [lds0] "s"(lds0), [lds0v] "s"(lds0v), [lds_wave] "s"(lds_wave), [slot0] "s"(slot0)
@@ -379,6 +379,14 @@ FUNC = '''template <> struct FastLoop128<%(T)s, %(DEFF)d, %(MASKED)s> {
     }
 };
 '''
+
+
+def operands(ndb, nks, ld):
+    accs = [f'[oa{i}] "+a"(oa[{i}])' for i in range(ndb)] + [f'[ob{i}] "+a"(ob[{i}])' for i in range(ndb)]
+    accs += [f'[qa{i}] "+a"(qa[{i}])' for i in range(nks)] + [f'[qb{i}] "+a"(qb[{i}])' for i in range(nks)]
+    offs = [f'"{{v{KOFF + i}}}"(koff[{i}])' for i in range(ld)] + [f'"{{v{VOFF + i}}}"(voff[{i}])' for i in range(ld)]
+    join = lambda xs: (",\n              ".join(", ".join(xs[i:i + 4]) for i in range(0, len(xs), 4)))
+    return join(accs), join(offs)
 
 
 def render(lines):
@@ -398,17 +406,23 @@ def main():
     if "--ablate" in sys.argv:
         ABLATE = int(sys.argv[sys.argv.index("--ablate") + 1])
         path = sys.argv[sys.argv.index("--out") + 1]
-    clob = "".join(f', "v{i}"' for i in list(range(64, 112)) + list(range(126, 134)))
-    global DEFF, KSTEPS, NSTEP, MASKED
+    global D, ROWB, TILE, LD, DEFF, KSTEPS, NSTEP, MASKED
     text = HEADER
-    for masked in (False, True):
-        for deff in (128, 96):
-            DEFF, KSTEPS, NSTEP, MASKED = deff, deff // 16, 2 * (deff // 32), masked
-            for T, mf, cvt in (("__bf16", "v_mfma_f32_32x32x16_bf16", cvt_bf16), ("_Float16", "v_mfma_f32_32x32x16_f16", cvt_f16)):
-                lines = gen_block(mf, cvt)
-                text += "\n" + FUNC % {"T": T, "DEFF": deff, "MASKED": "true" if masked else "false", "body": render(lines),
-                                       "clobbers": clob + (', "v139"' if masked else ""), "vregion": 3 * TILE,
-                                       "maskout": ', "+{v137}"(ra), "+{v138}"(rb)' if masked else ""}
+    # (head-dim tile, dims contracted, masked variant?)
+    configs = [(128, 128, False), (128, 96, False), (128, 128, True), (128, 96, True), (64, 64, False), (64, 64, True)]
+    for d, deff, masked in configs:
+        D, ROWB, TILE, LD = d, d * 2, 64 * d * 2, d // 32
+        DEFF, KSTEPS, NSTEP, MASKED = deff, deff // 16, 2 * (deff // 32), masked
+        unused = [KOFF + i for i in range(LD, 4)] + [VOFF + i for i in range(LD, 4)]  # (no inputs there at LD = 2)
+        clob = "".join(f', "v{i}"' for i in list(range(64, 112)) + unused + list(range(126, 134)))
+        for T, mf, cvt in (("__bf16", "v_mfma_f32_32x32x16_bf16", cvt_bf16), ("_Float16", "v_mfma_f32_32x32x16_f16", cvt_f16)):
+            lines = gen_block(mf, cvt)
+            accs, offs = operands(d // 32, d // 16, LD)
+            struct = (f"FastLoop128<{T}, {deff}, {'true' if masked else 'false'}>" if d == 128 else
+                      f"FastLoop64<{T}, {'true' if masked else 'false'}>")
+            text += "\n" + FUNC % {"STRUCT": struct, "NDB": d // 32, "NKS": d // 16, "LD": LD, "accs": accs, "offs": offs,
+                                   "body": render(lines), "clobbers": clob + (', "v139"' if masked else ""),
+                                   "vregion": 3 * TILE, "maskout": ', "+{v137}"(ra), "+{v138}"(rb)' if masked else ""}
     text += "\n}  // namespace fa\n"
     if "--check" in sys.argv:
         sys.exit(0 if os.path.exists(path) and open(path).read() == text else 1)
