@@ -986,17 +986,25 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     // last half-step index whose scores need no mask (for this wave), and the fast limit: every half-step
     // jj of a fast tile pair [j, j+4) needs jj + 1 <= fast_last
     int fast_last = -1;
-    if (!SOFTCAP && p.window_left < 0 && jend > 0 && !p.alibi) {
+    int fast_first = 0;  // first half-step index whose scores need no LEFT-window mask (0 without a left window)
+    if (!SOFTCAP && jend > 0 && !p.alibi) {
         int nomask = (sk - n_min * BLOCK_N) / 32 - 1;
         if (p.window_right >= 0) {
             const int t = wrow + shift + p.window_right - 31 - n_min * BLOCK_N;
             nomask = min(nomask, t >= 0 ? t / 32 : -1);
         }
         fast_last = min(nomask, jend - 1);
+        if (p.window_left >= 0) {  // half-step jj needs no left mask iff its first key >= (last row of the wave) + shift - window_left
+            const int t = wrow + 63 + shift - p.window_left - n_min * BLOCK_N;
+            fast_first = t > 0 ? (t + 31) / 32 : 0;
+        }
     }
     fast_last = __builtin_amdgcn_readfirstlane(fast_last);
-    // masks the generated block can apply itself: sequence end, causal / right window (no left window, ALiBi or softcap)
-    const bool mask_ok = !SOFTCAP && p.window_left < 0 && jend > 0 && !p.alibi;
+    fast_first = __builtin_amdgcn_readfirstlane(fast_first);
+    // masks the generated block can apply itself: sequence end, causal / right window (no ALiBi or softcap; under a left
+    // window only behind its edge: from_ok)
+    const bool mask_ok = !SOFTCAP && jend > 0 && !p.alibi;
+    auto from_ok = [&](int jt) { return jt + 1 >= fast_first; };  // the scores a block starting at jt computes are S(jt + 1) ...
 
     // Driver.  ONE call site of generic_half (its body is large; inlining it twice wrecks register allocation).
     auto to_canonical_after_odd = [&]() {  // after a KB = 0 fast half-step the next scores / P_A live in sby / pay
@@ -1008,18 +1016,18 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     int j = 0;
     // A tile whose first half-step is jt may take the fast path when both its half-steps (and the one behind them) need
     // no mask.
-    auto tile_ok = [&](int jt) { return jt + 2 <= fast_last; };
+    auto tile_ok = [&](int jt) { return jt + 2 <= fast_last && from_ok(jt); };
     bool first = true;  // the prologue leaves the pipeline state a fast tile expects: tile 0 may go straight to the fast loop
     while (j < J) {
         // generic until the next tile boundary (at least one half-step, except in front of tile 0: guarantees progress)
-        if (!(first && (tile_ok(0) || (mask_ok && jend > 0)))) {
+        if (!(first && (tile_ok(0) || (mask_ok && from_ok(0) && jend > 0)))) {
             do {
                 generic_half(j);
                 ++j;
             } while ((j & 1) != 0 && j < J);
         }
         first = false;
-        if ((!tile_ok(j) && !(mask_ok && (j & 1) == 0 && j < jend)) || moved_a || redo_a) continue;
+        if ((!tile_ok(j) && !(mask_ok && from_ok(j) && (j & 1) == 0 && j < jend)) || moved_a || redo_a) continue;
         {   // B(j) must be safe to exponentiate with its stale max (inside the loop the look-ahead guarantees it)
             float xa, xb;
             rowmax16(sbx, m_b, xa, xb);
@@ -1103,7 +1111,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
             // sequence that is not a multiple of 64 -- in the MASKED form of the block (the fresh scores get the mask, two
             // VALU instructions per score, before anything reads them).  Whole tiles: a trailing half-step the wave does not
             // need is fully masked and contributes exact zeros; the last half-step's P_A is a phantom as above.
-            if (addr32 && mask_ok && !tripped && (j & 1) == 0 && j < jend && !(FA_ABLATE & 128))
+            if (addr32 && mask_ok && from_ok(j) && !tripped && (j & 1) == 0 && j < jend && !(FA_ABLATE & 128))
                 run_block(std::true_type{}, (jend + 1 - j) >> 1, true);
         }
         // fast: up to three tiles (one turn of the LDS rings) per iteration; the first turn starts at the ring slot of

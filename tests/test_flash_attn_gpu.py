@@ -185,6 +185,24 @@ def test_head_dims(d, causal):
     _check(out, out_ref, out_pt, f"d={d}")
 
 
+@pytest.mark.parametrize("d", [64, 128])
+@pytest.mark.parametrize("window", [(300, 0), (256, 100), (700, -1), (130, 64)])
+@pytest.mark.parametrize("sq,sk", [(1536, 1536), (1200, 1700)])
+def test_sliding_window_long(sq, sk, window, d):
+    """Windows much shorter than the sequence: behind the left edge of a wave's key range the generated loop takes over (the
+    tiles between the two window edges need no mask), the MASKED block does the diagonal; the left-edge tiles stay generic."""
+    fa = _api()
+    torch.manual_seed(5)
+    q = torch.randn(1, sq, 2, d, dtype=torch.bfloat16)
+    k = torch.randn(1, sk, 2, d, dtype=torch.bfloat16)
+    v = torch.randn(1, sk, 2, d, dtype=torch.bfloat16)
+    out, lse, _ = fa.flash_attn_func(q.to(DEV), k.to(DEV), v.to(DEV), window_size=window, return_attn_probs=True)
+    ref_window = (window[0], sk) if (window[0] >= 0 and window[1] < 0) else window
+    out_ref, out_pt, lse_ref = _dense_ref(q, k, v, window_size=ref_window)
+    _check(out, out_ref, out_pt, f"window={window} d={d}")
+    _check_lse(lse, lse_ref)
+
+
 @pytest.mark.parametrize("window", [(64, 0), (16, 16), (0, 32), (300, -1), (-1, 17), (0, 0)])
 @pytest.mark.parametrize("sq,sk", [(113, 203), (512, 512), (700, 333)])
 def test_local_window(sq, sk, window):
