@@ -49,8 +49,11 @@ int run_bwd(fa::BParams bp, int rows_q_max, int rows_k_max, hipStream_t stream) 
     // the 512-register budget of a lone wave.  dQ: 2 for D <= 128; dK/dV (two accumulator sets + K and V): 2 for D = 64
     // (at D = 128 two blocks would fill all 256 AGPRs with accumulators; hipcc then rotates the whole AGPR file
     //  through v_accvgpr_mov to find temporaries -- measured 3x slower and not worth fighting).
+    //  At D = 64 the plain problem -- no softcap / dropout / ALiBi -- takes the one-block form as well: that is the shape of the
+    //  generated tile loop, tools/gen_bwd_loop.py.)
     constexpr int NBQ = D <= 128 ? 2 : 1;
-    constexpr int NBK = D <= 64 ? 2 : 1;
+    constexpr int NBK2 = D <= 64 ? 2 : 1;
+    const bool one_block = D == 64 && !SOFTCAP && !DROPOUT && !bp.alibi;
     // 1. D = rowsum(dO * O)
     {
         const int64_t rows = bp.cu_seqlens_q ? (int64_t)bp.total_q : (int64_t)bp.b * bp.seqlen_q;
@@ -65,7 +68,8 @@ int run_bwd(fa::BParams bp, int rows_q_max, int rows_k_max, hipStream_t stream) 
     }
     // 2. dK, dV
     {
-        static std::atomic<uint64_t> attr{0};
+        static std::atomic<uint64_t> attr{0}, attr1{0};
+        const int NBK = one_block ? 1 : NBK2;
         bp.num_blocks = (rows_k_max + 128 * NBK - 1) / (128 * NBK);
         const int64_t tiles = (int64_t)bp.num_blocks * bp.h_k * bp.b;
         if (tiles > 0x7fffffff) return FA_ERR_BAD_SHAPE;
@@ -74,7 +78,8 @@ int run_bwd(fa::BParams bp, int rows_q_max, int rows_k_max, hipStream_t stream) 
             const int64_t grid = unit_grid(tiles, bp.num_blocks);
             if (grid > 0x7fffffff) return FA_ERR_BAD_SHAPE;
             bp.grid = (int32_t)grid;
-            const int st = launch_kernel(fa::bwd_dkdv_kernel<T, D, NBK, SOFTCAP, DROPOUT>, fa::smem_bytes_dkdv<D>(), attr, bp.grid, 256, bp, stream);
+            const int st = one_block ? launch_kernel(fa::bwd_dkdv_kernel<T, D, 1, SOFTCAP, DROPOUT>, fa::smem_bytes_dkdv<D>(), attr1, bp.grid, 256, bp, stream)
+                                     : launch_kernel(fa::bwd_dkdv_kernel<T, D, NBK2, SOFTCAP, DROPOUT>, fa::smem_bytes_dkdv<D>(), attr, bp.grid, 256, bp, stream);
             if (st != FA_OK) return st;
         }
     }

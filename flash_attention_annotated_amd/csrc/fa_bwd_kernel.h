@@ -451,7 +451,7 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_kernel(const BParams p) {
         // the generated asm block (fa_bwd_loop_gen.h; same LDS layout and barrier protocol, so the four waves choose
         // independently).  The tile behind a run must belong to the same head (the block prefetches it through the head's
         // buffer descriptors); the run's tiles lie fully inside the sequence.
-        if constexpr (D == 128 && NB == 1 && !SOFTCAP && !DROPOUT && DMA && !(FA_BWD_ABLATE & 1)) {
+        if constexpr ((D == 128 || D == 64) && NB == 1 && !SOFTCAP && !DROPOUT && DMA && !(FA_BWD_ABLATE & 1)) {
             const int row0 = tile_row0(it);
             const int left = num_m - it % num_m;  // tiles of this head from `it` on
             int hi_row = sq - BM;
@@ -490,7 +490,8 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_kernel(const BParams p) {
                 }
                 const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
                 const uint32_t stat0 = lds0 + 4 * TILE_BYTES;
-                BwdLoop128<T>::run(dk_acc, dv_acc, kf[0], vf[0], (uint32_t)kbase, (uint32_t)vbase, qoffb, goffb,
+                using Loop = std::conditional_t<D == 128, BwdLoop128<T>, BwdLoop64<T>>;
+                Loop::run(dk_acc, dv_acc, kf[0], vf[0], (uint32_t)kbase, (uint32_t)vbase, qoffb, goffb,
                                    stat0 + 16 * hh, (uint32_t)lane * 4u, stat0 + (odd ? 2 * BM * 4 : 0) + lane * 4, p.scale_log2,
                                    odd ? 1.f : LOG2E, qdesc, gdesc, sdesc, (uint32_t)((row0 + BM) * q_rs * 2),
                                    (uint32_t)((row0 + BM) * g_rs * 2), (uint32_t)((row0 + BM) * 4), (uint32_t)(BM * q_rs * 2),
@@ -687,7 +688,7 @@ constexpr int smem_bytes_dkdv() {
     return tiles > o ? tiles : o;
 }
 
-template <int D> constexpr int dq_nbuf() { return D == 128 ? 3 : 2; }  // K / V LDS slots of bwd_dq_kernel
+template <int D> constexpr int dq_nbuf() { return D <= 128 ? 3 : 2; }  // K / V LDS slots of bwd_dq_kernel
 
 // ------------------------------------------------------------------------------------------------------------------
 // dQ.  NB = 32-row query blocks per wave (K / V / K^T fragments from LDS feed NB MFMAs each).
@@ -707,7 +708,7 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_kernel(const BParams p) {
     constexpr int O_ROW_BYTES = D * 2 + 16;
     constexpr float LOG2E = 1.4426950408889634f;
 
-    // [K0 .. K(NBUF-1) | V0 .. V(NBUF-1)]: two slots, three at head dim 128 (the generated block reads a tile's K one barrier
+    // [K0 .. K(NBUF-1) | V0 .. V(NBUF-1)]: two slots, three at head dims <= 128 (the generated block reads a tile's K one barrier
     // longer than the C++ path: see tools/gen_bwd_dq_loop.py)
     constexpr int NBUF = dq_nbuf<D>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -858,7 +859,7 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_kernel(const BParams p) {
         const int nxt = (cur + 1) % NBUF;
         // The bulk of the sweep at head dim 128: runs of tiles with nothing to mask for this wave's rows go through the
         // generated asm block (fa_bwd_dq_loop_gen.h; same barrier / LDS-DMA protocol, so the four waves choose independently).
-        if constexpr (D == 128 && NB == 2 && !SOFTCAP && !DROPOUT && DMA && !(FA_BWD_ABLATE & 2)) {
+        if constexpr ((D == 128 || D == 64) && NB == 2 && !SOFTCAP && !DROPOUT && DMA && !(FA_BWD_ABLATE & 2)) {
             int n_hi = sk / BLOCK_N - 1;  // last tile fully inside the keys
             if (p.window_right >= 0) {
                 const int lim = wrow + shift + p.window_right - (BLOCK_N - 1);  // first key of the tile <= lim
@@ -891,7 +892,8 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_kernel(const BParams p) {
                     voffb[i] = v_off[i] - 1024u * i;
                 }
                 const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
-                BwdDqLoop128<T>::run(dq_acc, qf[0], qf[1], gf[0], gf[1], lse2[0], lse2[1], dsum[0], dsum[1], (uint32_t)kbase,
+                using Loop = std::conditional_t<D == 128, BwdDqLoop128<T>, BwdDqLoop64<T>>;
+                Loop::run(dq_acc, qf[0], qf[1], gf[0], gf[1], lse2[0], lse2[1], dsum[0], dsum[1], (uint32_t)kbase,
                                      (uint32_t)vbase, koffb, voffb, p.scale_log2, kdesc, vdesc,
                                      (uint32_t)((n + 1) * BLOCK_N * k_rs * 2), (uint32_t)((n + 1) * BLOCK_N * v_rs * 2),
                                      (uint32_t)(BLOCK_N * k_rs * 2), (uint32_t)(BLOCK_N * v_rs * 2), lds0, lds_wave, cur, count);

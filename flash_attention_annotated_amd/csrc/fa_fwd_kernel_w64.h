@@ -1001,9 +1001,11 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     }
     fast_last = __builtin_amdgcn_readfirstlane(fast_last);
     fast_first = __builtin_amdgcn_readfirstlane(fast_first);
-    // masks the generated block can apply itself: sequence end, causal / right window (no ALiBi or softcap; under a left
-    // window only behind its edge: from_ok)
-    const bool mask_ok = !SOFTCAP && jend > 0 && !p.alibi;
+    // masks the generated block can apply itself: sequence end, causal / right window (no ALiBi or softcap)
+    // (the MASKED block stays off under a left window: with it, a rare data-dependent case -- 2 of 24 (seed, head) cases of
+    //  tests/test_flash_attn_gpu.py::test_sliding_window_seeds -- lost one half-step's row sum on the rows whose first visible
+    //  half-step is partly masked; not understood yet, the diagonal tiles of a sliding window therefore take the generic path)
+    const bool mask_ok = !SOFTCAP && jend > 0 && !p.alibi && p.window_left < 0;
     auto from_ok = [&](int jt) { return jt + 1 >= fast_first; };  // the scores a block starting at jt computes are S(jt + 1) ...
 
     // Driver.  ONE call site of generic_half (its body is large; inlining it twice wrecks register allocation).

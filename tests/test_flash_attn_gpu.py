@@ -203,6 +203,22 @@ def test_sliding_window_long(sq, sk, window, d):
     _check_lse(lse, lse_ref)
 
 
+@pytest.mark.parametrize("sq,sk,window", [(448, 704, (96, 64)), (640, 640, (130, 0)), (512, 768, (200, 40))])
+def test_sliding_window_seeds(sq, sk, window):
+    """Twelve data sets per shape (GQA 4/2, head dim 128): the hand-off between the generic half-steps at the left window edge
+    and the generated block depends on the data (guard trips, rows whose first visible half-step is partly masked)."""
+    fa = _api()
+    for seed in range(12):
+        torch.manual_seed(seed)
+        q = torch.randn(1, sq, 4, 128, dtype=torch.bfloat16)
+        k = torch.randn(1, sk, 2, 128, dtype=torch.bfloat16)
+        v = torch.randn(1, sk, 2, 128, dtype=torch.bfloat16)
+        out, lse, _ = fa.flash_attn_func(q.to(DEV), k.to(DEV), v.to(DEV), window_size=window, return_attn_probs=True)
+        out_ref, out_pt, lse_ref = _dense_ref(q, k, v, window_size=window)
+        _check(out, out_ref, out_pt, f"window={window} seed={seed}")
+        _check_lse(lse, lse_ref)
+
+
 @pytest.mark.parametrize("window", [(64, 0), (16, 16), (0, 32), (300, -1), (-1, 17), (0, 0)])
 @pytest.mark.parametrize("sq,sk", [(113, 203), (512, 512), (700, 333)])
 def test_local_window(sq, sk, window):

@@ -158,10 +158,11 @@ def group_sdp(E, slot, kb, uid, valu_kb, dma_slot, nxt):
         sl.slot(4 * ks + 2)
         E.e(f"{mf} {v(d1, 16)}, {v(VR + 4 * (ks % 3), 4)}, %[gb{ks}], {c(d1)}")
         sl.slot(4 * ks + 3)
-        if ks + 2 >= KSTEPS and nxt[0] == "row":
-            # (prologue only: the next group reads the same rings, whose positions 0 / 1 hold the fragments of steps 6 / 7 until
-            #  the MFMAs above have issued)
-            fetch_first(E, nxt, ks + 2 - KSTEPS)
+        if ks == KSTEPS - 1 and nxt[0] == "row":
+            # (prologue only: the next group reads the same rings, whose positions 0 / 1 hold fragments of this group's last
+            #  steps until the MFMAs above have issued)
+            fetch_first(E, nxt, 0)
+            fetch_first(E, nxt, 1)
     if dma_slot is not None:
         E.e("s_add_u32 %[ktile], %[ktile], %[kstep]")
         E.e("s_add_u32 %[vtile], %[vtile], %[vstep]")
@@ -195,7 +196,7 @@ def group_dq(E, slot, kb, uid, barrier, nxt):
             fetch_first(E, nxt, t + 2 - NSTEP)
         E.wait_for(("t", uid, t))
         E.e(f"{mf} %[dq{db}], {v(KT + 4 * (t % 3), 4)}, {v(DSF[kb] + 4 * st, 4)}, %[dq{db}]")
-        E.e(f"{mf} %[dq{4 + db}], {v(KT + 4 * (t % 3), 4)}, {v(DSF[kb] + 8 + 4 * st, 4)}, %[dq{4 + db}]")
+        E.e(f"{mf} %[dq{D // 32 + db}], {v(KT + 4 * (t % 3), 4)}, {v(DSF[kb] + 8 + 4 * st, 4)}, %[dq{D // 32 + db}]")
 
 
 def gen_block(mfma, cvt):
@@ -278,38 +279,38 @@ HEADER = '''// GENERATED by tools/gen_bwd_dq_loop.py -- do not edit; regenerate 
 namespace fa {
 
 template <typename T> struct BwdDqLoop128;
+template <typename T> struct BwdDqLoop64;   // head dim 64: LDS rows of 128 B, 4 k-steps, 2 dQ blocks per row block, 2 LDS-DMA pieces per wave
 '''
 
-FUNC = '''template <> struct BwdDqLoop128<%(T)s> {
-    static __device__ __forceinline__ void run(f32x16 (&dq)[8], const u32x4 (&qa)[8], const u32x4 (&qb)[8], const u32x4 (&ga)[8],
-                                               const u32x4 (&gb)[8], float lse_a, float lse_b, float dsum_a, float dsum_b,
-                                               uint32_t kbase, uint32_t vbase, const uint32_t (&koff)[4],
-                                               const uint32_t (&voff)[4], float csc, u32x4 kdesc, u32x4 vdesc, uint32_t ktile,
+FUNC = '''template <> struct BwdDqLoop%(D)d<%(T)s> {
+    static __device__ __forceinline__ void run(f32x16 (&dq)[%(NACC)d], const u32x4 (&qa)[%(NKS)d], const u32x4 (&qb)[%(NKS)d], const u32x4 (&ga)[%(NKS)d],
+                                               const u32x4 (&gb)[%(NKS)d], float lse_a, float lse_b, float dsum_a, float dsum_b,
+                                               uint32_t kbase, uint32_t vbase, const uint32_t (&koff)[%(LD)d],
+                                               const uint32_t (&voff)[%(LD)d], float csc, u32x4 kdesc, u32x4 vdesc, uint32_t ktile,
                                                uint32_t vtile, uint32_t kstep, uint32_t vstep, uint32_t lds0, uint32_t lds_wave,
                                                int slot0, int count) {
         uint32_t m0save;
         asm volatile(
 %(body)s
-            : [dq0] "+a"(dq[0]), [dq1] "+a"(dq[1]), [dq2] "+a"(dq[2]), [dq3] "+a"(dq[3]),
-              [dq4] "+a"(dq[4]), [dq5] "+a"(dq[5]), [dq6] "+a"(dq[6]), [dq7] "+a"(dq[7]),
+            : %(accs)s,
               [ktile] "+s"(ktile), [vtile] "+s"(vtile), [count] "+s"(count), [m0save] "=&s"(m0save)
-            : [qa0] "a"(qa[0]), [qa1] "a"(qa[1]), [qa2] "a"(qa[2]), [qa3] "a"(qa[3]),
-              [qa4] "a"(qa[4]), [qa5] "a"(qa[5]), [qa6] "a"(qa[6]), [qa7] "a"(qa[7]),
-              [qb0] "a"(qb[0]), [qb1] "a"(qb[1]), [qb2] "a"(qb[2]), [qb3] "a"(qb[3]),
-              [qb4] "a"(qb[4]), [qb5] "a"(qb[5]), [qb6] "a"(qb[6]), [qb7] "a"(qb[7]),
-              [ga0] "a"(ga[0]), [ga1] "a"(ga[1]), [ga2] "a"(ga[2]), [ga3] "a"(ga[3]),
-              [ga4] "a"(ga[4]), [ga5] "a"(ga[5]), [ga6] "a"(ga[6]), [ga7] "a"(ga[7]),
-              [gb0] "a"(gb[0]), [gb1] "a"(gb[1]), [gb2] "a"(gb[2]), [gb3] "a"(gb[3]),
-              [gb4] "a"(gb[4]), [gb5] "a"(gb[5]), [gb6] "a"(gb[6]), [gb7] "a"(gb[7]),
+            : %(frags)s,
               "{v220}"(lse_a), "{v221}"(lse_b), "{v222}"(dsum_a), "{v223}"(dsum_b), "{v224}"(kbase), "{v225}"(vbase),
-              "{v212}"(koff[0]), "{v213}"(koff[1]), "{v214}"(koff[2]), "{v215}"(koff[3]),
-              "{v216}"(voff[0]), "{v217}"(voff[1]), "{v218}"(voff[2]), "{v219}"(voff[3]),
+              %(offs)s,
               [csc] "s"(csc), [kdesc] "s"(kdesc), [vdesc] "s"(vdesc), [kstep] "s"(kstep), [vstep] "s"(vstep),
               [lds0] "s"(lds0), [lds_wave] "s"(lds_wave), [slot0] "s"(slot0)
             : "memory", "scc"%(clobbers)s);
     }
 };
 '''
+
+
+def operands(nacc, nks, ld):
+    join = lambda xs: (",\n              ".join(", ".join(xs[i:i + 4]) for i in range(0, len(xs), 4)))
+    accs = [f'[dq{i}] "+a"(dq[{i}])' for i in range(nacc)]
+    frags = [f'[{n}{i}] "a"({n}[{i}])' for n in ("qa", "qb", "ga", "gb") for i in range(nks)]
+    offs = [f'"{{v{KOFF + i}}}"(koff[{i}])' for i in range(ld)] + [f'"{{v{VOFF + i}}}"(voff[{i}])' for i in range(ld)]
+    return join(accs), join(frags), join(offs)
 
 
 def render(lines):
@@ -322,10 +323,17 @@ def render(lines):
 def main():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     path = os.path.join(root, "flash_attention_annotated_amd", "csrc", "fa_bwd_dq_loop_gen.h")
-    clob = "".join(f', "v{i}"' for i in list(range(212)) + list(range(RV, NVGPR)))
+    global D, ROWB, TILE, VREG, KSTEPS, NSTEP, LD
     text = HEADER
-    for T, mf, cvt in (("__bf16", "v_mfma_f32_32x32x16_bf16", cvt_bf16), ("_Float16", "v_mfma_f32_32x32x16_f16", cvt_f16)):
-        text += "\n" + FUNC % {"T": T, "body": render(gen_block(mf, cvt)), "clobbers": clob}
+    for d in (128, 64):
+        D, ROWB, TILE, KSTEPS, NSTEP, LD = d, d * 2, 64 * d * 2, d // 16, 2 * (d // 32), d // 32
+        VREG = NSLOT * TILE
+        unused = [KOFF + i for i in range(LD, 4)] + [VOFF + i for i in range(LD, 4)]  # (no inputs there at LD = 2)
+        clob = "".join(f', "v{i}"' for i in list(range(212)) + unused + list(range(RV, NVGPR)))
+        accs, frags, offs = operands(2 * (d // 32), KSTEPS, LD)
+        for T, mf, cvt in (("__bf16", "v_mfma_f32_32x32x16_bf16", cvt_bf16), ("_Float16", "v_mfma_f32_32x32x16_f16", cvt_f16)):
+            text += "\n" + FUNC % {"T": T, "D": d, "NACC": 2 * (d // 32), "NKS": KSTEPS, "LD": LD, "accs": accs, "frags": frags,
+                                   "offs": offs, "body": render(gen_block(mf, cvt)), "clobbers": clob}
     text += "\n}  // namespace fa\n"
     if "--check" in sys.argv:
         sys.exit(0 if os.path.exists(path) and open(path).read() == text else 1)

@@ -126,7 +126,8 @@ def pointwise(E, rb, uid, c):
 
 class Slots:
     """Hands the pointwise items out over the issue slots of a 16-MFMA group (slots `first`..15)."""
-    def __init__(self, E, items, first=2, nslots=16):
+    def __init__(self, E, items, first=2, nslots=None):
+        nslots = nslots or 2 * KSTEPS
         self.E, self.items, self.first, self.nslots = E, list(items), first, nslots
         n = sum(1 for it in self.items if not isinstance(it, tuple))
         self.per = -(-n // max(1, nslots - first))
@@ -163,7 +164,7 @@ def group_sdp(E, c, rb, uid, valu, dma):
     if dma:
         E.e(f"s_add_u32 m0, %[lds_wave], {n * TILE}")
     for ks in range(KSTEPS):
-        pos = 8 * rb + ks
+        pos = KSTEPS * rb + ks
         if ks + 2 < KSTEPS:
             E.row_frag(QR, pos + 2, ks + 2, qb, ("q", uid, rb, ks + 2))
             E.row_frag(GR, pos + 2, ks + 2, gb, ("g", uid, rb, ks + 2))
@@ -213,7 +214,7 @@ def group_dvdk(E, c, rb, uid, valu, last, next_uid=None):
     E.e("s_nop 1")   # VALU-packed P / dS -> MFMA operand
     for t in range(NSTEP):
         db, st = t >> 1, t & 1
-        pos = 8 * rb + t
+        pos = NSTEP * rb + t
         if last and t == NSTEP - 2:
             # tile barrier, two steps early: every read of this tile's buffers has been issued; the next tile's LDS-DMA pieces
             # (issued in group A) have long landed; its LSE / D row goes to LDS here
@@ -303,28 +304,24 @@ HEADER = '''// GENERATED by tools/gen_bwd_loop.py -- do not edit; regenerate wit
 namespace fa {
 
 template <typename T> struct BwdLoop128;
+template <typename T> struct BwdLoop64;   // head dim 64: LDS rows of 128 B, 4 k-steps, 2 blocks per accumulator, 2 LDS-DMA pieces per wave
 '''
 
-FUNC = '''template <> struct BwdLoop128<%(T)s> {
-    static __device__ __forceinline__ void run(f32x16 (&dk)[4], f32x16 (&dv)[4], const u32x4 (&kf)[8], const u32x4 (&vf)[8],
-                                               uint32_t kbase, uint32_t vbase, const uint32_t (&qoff)[4],
-                                               const uint32_t (&goff)[4], uint32_t saddr, uint32_t soff, uint32_t slds, float csc,
+FUNC = '''template <> struct BwdLoop%(D)d<%(T)s> {
+    static __device__ __forceinline__ void run(f32x16 (&dk)[%(NDB)d], f32x16 (&dv)[%(NDB)d], const u32x4 (&kf)[%(NKS)d], const u32x4 (&vf)[%(NKS)d],
+                                               uint32_t kbase, uint32_t vbase, const uint32_t (&qoff)[%(LD)d],
+                                               const uint32_t (&goff)[%(LD)d], uint32_t saddr, uint32_t soff, uint32_t slds, float csc,
                                                float sfac, u32x4 qdesc, u32x4 gdesc, u32x4 sdesc, uint32_t qtile, uint32_t gtile,
                                                uint32_t stile, uint32_t qstep, uint32_t gstep, uint32_t lds0, uint32_t lds_wave,
                                                int buf0, int count) {
         uint32_t m0save;
         asm volatile(
 %(body)s
-            : [dk0] "+a"(dk[0]), [dk1] "+a"(dk[1]), [dk2] "+a"(dk[2]), [dk3] "+a"(dk[3]),
-              [dv0] "+a"(dv[0]), [dv1] "+a"(dv[1]), [dv2] "+a"(dv[2]), [dv3] "+a"(dv[3]),
+            : %(accs)s,
               [qtile] "+s"(qtile), [gtile] "+s"(gtile), [stile] "+s"(stile), [count] "+s"(count), [m0save] "=&s"(m0save)
-            : [kf0] "a"(kf[0]), [kf1] "a"(kf[1]), [kf2] "a"(kf[2]), [kf3] "a"(kf[3]),
-              [kf4] "a"(kf[4]), [kf5] "a"(kf[5]), [kf6] "a"(kf[6]), [kf7] "a"(kf[7]),
-              [vf0] "a"(vf[0]), [vf1] "a"(vf[1]), [vf2] "a"(vf[2]), [vf3] "a"(vf[3]),
-              [vf4] "a"(vf[4]), [vf5] "a"(vf[5]), [vf6] "a"(vf[6]), [vf7] "a"(vf[7]),
+            : %(frags)s,
               "{v208}"(kbase), "{v209}"(vbase),
-              "{v192}"(qoff[0]), "{v193}"(qoff[1]), "{v194}"(qoff[2]), "{v195}"(qoff[3]),
-              "{v196}"(goff[0]), "{v197}"(goff[1]), "{v198}"(goff[2]), "{v199}"(goff[3]),
+              %(offs)s,
               "{v200}"(saddr), "{v202}"(soff), "{v203}"(slds),
               [csc] "s"(csc), [sfac] "s"(sfac), [qdesc] "s"(qdesc), [gdesc] "s"(gdesc), [sdesc] "s"(sdesc),
               [qstep] "s"(qstep), [gstep] "s"(gstep), [lds0] "s"(lds0), [lds_wave] "s"(lds_wave), [buf0] "s"(buf0)
@@ -332,6 +329,14 @@ FUNC = '''template <> struct BwdLoop128<%(T)s> {
     }
 };
 '''
+
+
+def operands(ndb, nks, ld):
+    join = lambda xs: (",\n              ".join(", ".join(xs[i:i + 4]) for i in range(0, len(xs), 4)))
+    accs = [f'[dk{i}] "+a"(dk[{i}])' for i in range(ndb)] + [f'[dv{i}] "+a"(dv[{i}])' for i in range(ndb)]
+    frags = [f'[{n}{i}] "a"({n}[{i}])' for n in ("kf", "vf") for i in range(nks)]
+    offs = [f'"{{v{QOFF + i}}}"(qoff[{i}])' for i in range(ld)] + [f'"{{v{GOFF + i}}}"(goff[{i}])' for i in range(ld)]
+    return join(accs), join(frags), join(offs)
 
 
 def render(lines):
@@ -351,11 +356,17 @@ def main():
     if "--ablate" in sys.argv:
         ABLATE = int(sys.argv[sys.argv.index("--ablate") + 1])
         path = sys.argv[sys.argv.index("--out") + 1]
-    inputs = set(range(192, 200)) | {200, 202, 203, 208, 209}
-    clob = "".join(f', "v{i}"' for i in range(NVGPR) if i not in inputs)
+    global D, ROWB, TILE, STAT, KSTEPS, NSTEP, LD
     text = HEADER
-    for T, mf, cvt in (("__bf16", "v_mfma_f32_32x32x16_bf16", cvt_bf16), ("_Float16", "v_mfma_f32_32x32x16_f16", cvt_f16)):
-        text += "\n" + FUNC % {"T": T, "body": render(gen_block(mf, cvt)), "clobbers": clob}
+    for d in (128, 64):
+        D, ROWB, TILE, KSTEPS, NSTEP, LD = d, d * 2, 64 * d * 2, d // 16, 2 * (d // 32), d // 32
+        STAT = 4 * TILE
+        inputs = set(range(QOFF, QOFF + LD)) | set(range(GOFF, GOFF + LD)) | {200, 202, 203, 208, 209}
+        clob = "".join(f', "v{i}"' for i in range(NVGPR) if i not in inputs)
+        accs, frags, offs = operands(d // 32, KSTEPS, LD)
+        for T, mf, cvt in (("__bf16", "v_mfma_f32_32x32x16_bf16", cvt_bf16), ("_Float16", "v_mfma_f32_32x32x16_f16", cvt_f16)):
+            text += "\n" + FUNC % {"T": T, "D": d, "NDB": d // 32, "NKS": KSTEPS, "LD": LD, "accs": accs, "frags": frags, "offs": offs,
+                                   "body": render(gen_block(mf, cvt)), "clobbers": clob}
     text += "\n}  // namespace fa\n"
     if "--check" in sys.argv:
         sys.exit(0 if os.path.exists(path) and open(path).read() == text else 1)
