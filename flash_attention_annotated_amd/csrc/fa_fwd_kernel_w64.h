@@ -1005,7 +1005,10 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     // (the MASKED block stays off under a left window: with it, a rare data-dependent case -- 2 of 24 (seed, head) cases of
     //  tests/test_flash_attn_gpu.py::test_sliding_window_seeds -- lost one half-step's row sum on the rows whose first visible
     //  half-step is partly masked; not understood yet, the diagonal tiles of a sliding window therefore take the generic path)
-    const bool mask_ok = !SOFTCAP && jend > 0 && !p.alibi && p.window_left < 0;
+#ifndef FA_WINMASK
+#define FA_WINMASK 0  // developer-only: 1 = MASKED block also under a left window, 2 = ... without the l_a restore, 4 = ... one tile later
+#endif
+    const bool mask_ok = !SOFTCAP && jend > 0 && !p.alibi && (p.window_left < 0 || (FA_WINMASK & 1));
     auto from_ok = [&](int jt) { return jt + 1 >= fast_first; };  // the scores a block starting at jt computes are S(jt + 1) ...
 
     // Driver.  ONE call site of generic_half (its body is large; inlining it twice wrecks register allocation).
@@ -1113,8 +1116,9 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
             // sequence that is not a multiple of 64 -- in the MASKED form of the block (the fresh scores get the mask, two
             // VALU instructions per score, before anything reads them).  Whole tiles: a trailing half-step the wave does not
             // need is fully masked and contributes exact zeros; the last half-step's P_A is a phantom as above.
-            if (addr32 && mask_ok && from_ok(j) && !tripped && (j & 1) == 0 && j < jend && !(FA_ABLATE & 128))
-                run_block(std::true_type{}, (jend + 1 - j) >> 1, true);
+            if (addr32 && mask_ok && from_ok((FA_WINMASK & 4) && p.window_left >= 0 ? j - 2 : j) && !tripped && (j & 1) == 0 && j < jend &&
+                !(FA_ABLATE & 128))
+                run_block(std::true_type{}, (jend + 1 - j) >> 1, !((FA_WINMASK & 2) && p.window_left >= 0));
         }
         // fast: up to three tiles (one turn of the LDS rings) per iteration; the first turn starts at the ring slot of
         // tile j/2 (`skip` slots are already behind us); every fast tile issues 2 LD_PER_THREAD LDS-DMA pieces, one per
