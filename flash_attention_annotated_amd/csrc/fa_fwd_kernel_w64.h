@@ -344,6 +344,11 @@ __device__ __forceinline__ void drain_scores(f32x16 &s0, f32x16 &s1) {
 #ifndef FA_ABLATE
 #define FA_ABLATE 0
 #endif
+// developer-only (the open sliding-window / MASKED-block question, see mask_ok): 1 = MASKED block also under a left window,
+// 2 = ... without the l_a restore, 4 = ... one tile later
+#ifndef FA_WINMASK
+#define FA_WINMASK 0
+#endif
 
 // Developer-only phase timestamps (never shipped: -DFA_TIMING builds, tools/wg_phases.py): every wave drops the 100 MHz
 // wall clock into 64 spare LDS bytes (per wave) behind the K/V rings (LDS traffic only: the loop's manual vmcnt accounting is not
@@ -1005,9 +1010,6 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     // (the MASKED block stays off under a left window: with it, a rare data-dependent case -- 2 of 24 (seed, head) cases of
     //  tests/test_flash_attn_gpu.py::test_sliding_window_seeds -- lost one half-step's row sum on the rows whose first visible
     //  half-step is partly masked; not understood yet, the diagonal tiles of a sliding window therefore take the generic path)
-#ifndef FA_WINMASK
-#define FA_WINMASK 0  // developer-only: 1 = MASKED block also under a left window, 2 = ... without the l_a restore, 4 = ... one tile later
-#endif
     const bool mask_ok = !SOFTCAP && jend > 0 && !p.alibi && (p.window_left < 0 || (FA_WINMASK & 1));
     auto from_ok = [&](int jt) { return jt + 1 >= fast_first; };  // the scores a block starting at jt computes are S(jt + 1) ...
 
