@@ -741,21 +741,19 @@ int fa_fwd(const fa_fwd_params *p, void *stream_) {
     if (tiles == 0) return FA_OK;  // nothing to compute (seqlen_q == 0)
     if (tiles > 0x7fffffff) return FA_ERR_BAD_SHAPE;
     kp.num_tiles = (int32_t)tiles;
-    // scheduling unit: everything that streams one (batch, kv head)'s K/V, unless that leaves fewer than two units
-    // per XCD; then one m_block of the GQA group (small problems: fill the chip first, L2 reuse second)
-    // -- and unless the (batch, kv head) units do not deal evenly over the 8 XCDs AND keeping a head on one XCD buys nothing:
-    // 20 units are 3 + 3 + 3 + 3 + 2 + 2 + 2 + 2, the launch takes as long as 24 (tools/hdim_bench.py: d192 b2 h10 non-causal 2.88
-    // ms instead of 2.41).  Dealing m_blocks round-robin fixes that but gives up the XCD's L2 as the head's K/V cache: measured
-    // worse wherever a head's K + V fit the 4 MiB L2 (d96 causal 915 -> 612 TFLOP/s) and under causal masks in general (d192
-    // causal 328 -> 267), so only non-causal problems whose heads do not fit take it.
+    // scheduling (tile_of_wg): whole (batch, kv head) units -- everything that streams one head's K/V stays on one XCD -- for as
+    // many units as deal evenly over the 8 XCDs, the remaining heads by m_block of the GQA group; problems with fewer than two
+    // units per XCD entirely by m_block (fill the chip first, L2 reuse second).  (20 units used to be dealt 3+3+3+3+2+2+2+2:
+    // the launch took as long as 24, tools/hdim_bench.py d192 b2 h10 2.88 ms instead of 2.41.)
     const int64_t bk_units = (int64_t)p->b * p->h_k;
-    const bool even = ((bk_units + 7) / 8) * 8 * 16 <= bk_units * 17;  // <= 1/16 of imbalance
-    const bool causal_like = p->is_causal || p->window_size_right >= 0;
-    const bool head_fits_l2 = (int64_t)p->seqlen_k * p->d * 2 * 2 <= (4ll << 20);
-    const bool whole_heads = bk_units >= 16 && (even || causal_like || head_fits_l2 || p->cu_seqlens_k != nullptr);
-    kp.unit_tiles = whole_heads ? kp.h_ratio * kp.num_m_blocks : kp.h_ratio;
-    const int64_t units = (tiles + kp.unit_tiles - 1) / kp.unit_tiles;
-    const int64_t grid = 8 * ((units + 7) / 8) * kp.unit_tiles;
+    const int64_t per_kvh = (int64_t)kp.h_ratio * kp.num_m_blocks;
+    const int64_t whole_units = bk_units >= 16 ? bk_units / 8 * 8 : 0;
+    kp.unit_tiles = (int32_t)per_kvh;
+    const int64_t whole_slots = whole_units / 8 * per_kvh;
+    const int64_t rem_units = (tiles - whole_slots * 8 + kp.h_ratio - 1) / kp.h_ratio;
+    const int64_t grid = 8 * (whole_slots + (rem_units + 7) / 8 * kp.h_ratio);
+    if (whole_slots > 0x7fffffff) return FA_ERR_BAD_SHAPE;
+    kp.whole_slots = (int32_t)whole_slots;
     if (grid > 0x7fffffff) return FA_ERR_BAD_SHAPE;
     kp.grid = (int32_t)grid;
     {   // compute units of the current device (cached per device ordinal)

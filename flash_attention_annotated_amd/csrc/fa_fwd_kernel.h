@@ -52,8 +52,9 @@ struct KParams {
     int32_t h_ratio;       // h / h_k
     int32_t num_m_blocks;  // ceil(seqlen_q / BLOCK_M)
     int32_t num_tiles;     // num_m_blocks * h * b  (work list length)
-    int32_t unit_tiles;    // tiles per scheduling unit (see decode_tile)
-    int32_t grid;          // workgroups launched = 8 * ceil(units / 8) * unit_tiles
+    int32_t unit_tiles;    // tiles per scheduling unit (see tile_of_wg)
+    int32_t whole_slots;   // workgroup slots per XCD dealt in units of unit_tiles; the slots behind them in units of h_ratio
+    int32_t grid;          // workgroups launched (a multiple of 8)
     int32_t num_cus;       // compute units of the device (one 256-thread workgroup of the pipelined kernels per CU)
     int32_t window_left, window_right;  // <0 unbounded; causal => right = 0
     float scale;           // softmax_scale (softcap: the softcap value)
@@ -185,12 +186,20 @@ constexpr int BLOCK_N = 64;  // keys per K/V tile
 // one after the other.  Sharing workgroups hit one L2 (HBM traffic ~ algorithmic bytes), and XCDs get the same number of
 // units of every batch entry, which balances ragged batches (a contiguous split gave whole sequences to single XCDs).
 // Placement is a speed matter only.  Returns false for padding workgroups.
+// Workgroup -> tile.  Workgroup ids go round-robin over the 8 XCDs (id & 7); an XCD's slots (id >> 3) first walk its share of
+// the (batch, kv head) units -- whole heads, so that an XCD's L2 holds one head's K/V at a time -- as far as those deal evenly
+// (whole_slots), then the remaining heads are dealt by m_block (units of the GQA group's h_ratio tiles), which keeps every
+// XCD equally loaded for any head count.
+__device__ __forceinline__ int tile_of_wg(const KParams &p, int wg) {
+    const int xcd = wg & 7, slot = wg >> 3;
+    if (slot < p.whole_slots) return ((slot / p.unit_tiles) * 8 + xcd) * p.unit_tiles + slot % p.unit_tiles;
+    const int s2 = slot - p.whole_slots;
+    return p.whole_slots * 8 + ((s2 / p.h_ratio) * 8 + xcd) * p.h_ratio + s2 % p.h_ratio;
+}
 __device__ __forceinline__ bool decode_tile(const KParams &p, int &m_block, int &head, int &batch, int &split) {
     split = p.num_splits > 1 ? blockIdx.x / p.grid : 0;  // p.grid is a multiple of 8: the XCD of a tile does not depend on the split
     const int wg = p.num_splits > 1 ? blockIdx.x % p.grid : blockIdx.x;
-    const int xcd = wg & 7, slot = wg >> 3;
-    const int unit = (slot / p.unit_tiles) * 8 + xcd;
-    const int tile = unit * p.unit_tiles + slot % p.unit_tiles;
+    const int tile = tile_of_wg(p, wg);
     if (tile >= p.num_tiles) return false;
     const int per_kvh = p.h_ratio * p.num_m_blocks;
     const int bk = tile / per_kvh, r = tile % per_kvh;

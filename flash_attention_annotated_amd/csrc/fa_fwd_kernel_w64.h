@@ -1213,8 +1213,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     FA_STAMP(51);  // key sweep done
     if (!p.cu_seqlens_q && !p.seqused_q && p.num_splits <= 1 && p.q_row_stride < (1 << 20)) {
         const int wg2 = blockIdx.x + p.num_cus;
-        const int slot2 = wg2 >> 3;
-        const int tile2 = ((slot2 / p.unit_tiles) * 8 + (wg2 & 7)) * p.unit_tiles + slot2 % p.unit_tiles;  // decode_tile()
+        const int tile2 = tile_of_wg(p, wg2);
         if (wg2 < p.grid && tile2 < p.num_tiles) {
             const int per_kvh = p.h_ratio * p.num_m_blocks;
             const int bk2 = tile2 / per_kvh, r2 = tile2 % per_kvh;

@@ -1,0 +1,48 @@
+"""The forward's workgroup -> tile map (csrc/fa_fwd_kernel.h: tile_of_wg, host side csrc/fa_fwd_api.hip) restated in Python: every
+tile is visited exactly once, padding workgroups fall outside, and the XCDs (workgroup id & 7) get equal shares for any head
+count -- whole (batch, kv head) units as far as they deal evenly, the remaining heads by m_block of the GQA group."""
+import pytest
+
+
+def host(b, h_k, h_ratio, num_m_blocks):
+    tiles = num_m_blocks * h_k * h_ratio * b
+    bk_units = b * h_k
+    per_kvh = h_ratio * num_m_blocks
+    whole_units = bk_units // 8 * 8 if bk_units >= 16 else 0
+    whole_slots = whole_units // 8 * per_kvh
+    rem_units = (tiles - whole_slots * 8 + h_ratio - 1) // h_ratio
+    grid = 8 * (whole_slots + (rem_units + 7) // 8 * h_ratio)
+    return tiles, per_kvh, whole_slots, grid
+
+
+def tile_of_wg(wg, unit_tiles, whole_slots, h_ratio):
+    xcd, slot = wg & 7, wg >> 3
+    if slot < whole_slots:
+        return ((slot // unit_tiles) * 8 + xcd) * unit_tiles + slot % unit_tiles
+    s2 = slot - whole_slots
+    return whole_slots * 8 + ((s2 // h_ratio) * 8 + xcd) * h_ratio + s2 % h_ratio
+
+
+@pytest.mark.parametrize("b,h_k,h_ratio,m", [(1, 1, 1, 1), (2, 10, 1, 64), (2, 21, 1, 32), (1, 12, 1, 7), (4, 16, 1, 32), (8, 8, 4, 5),
+                                             (3, 7, 2, 9), (1, 40, 1, 3), (5, 5, 8, 2), (2, 8, 1, 64), (1, 17, 3, 4)])
+def test_every_tile_once_and_xcds_balanced(b, h_k, h_ratio, m):
+    tiles, unit_tiles, whole_slots, grid = host(b, h_k, h_ratio, m)
+    assert grid % 8 == 0
+    seen, per_xcd = [], [0] * 8
+    for wg in range(grid):
+        t = tile_of_wg(wg, unit_tiles, whole_slots, h_ratio)
+        assert t >= 0
+        if t < tiles:
+            seen.append(t)
+            per_xcd[wg & 7] += 1
+    assert sorted(seen) == list(range(tiles))
+    # an XCD's share differs from another's by at most one GQA group's worth of tiles
+    assert max(per_xcd) - min(per_xcd) <= h_ratio
+    # the tiles of one (batch, kv head, m_block) GQA group always share an XCD
+    xcd_of = {}
+    for wg in range(grid):
+        t = tile_of_wg(wg, unit_tiles, whole_slots, h_ratio)
+        if t < tiles:
+            xcd_of[t] = wg & 7
+    for t0 in range(0, tiles, h_ratio):
+        assert len({xcd_of[t] for t in range(t0, t0 + h_ratio)}) == 1
