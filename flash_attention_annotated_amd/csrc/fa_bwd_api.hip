@@ -37,10 +37,13 @@ int launch_kernel(K kernel, int smem, std::atomic<uint64_t> &attr_set, int grid,
     return FA_OK;
 }
 
-// grid of decode_block(): units of `blocks` workgroups, 8 units (one per XCD) per round
-int64_t unit_grid(int64_t tiles, int blocks) {
-    const int64_t units = (tiles + blocks - 1) / blocks;
-    return 8 * ((units + 7) / 8) * blocks;
+// grid of decode_block(): whole units of `blocks` workgroups for as many (batch, head) units as deal evenly over the 8 XCDs,
+// the remaining heads block by block (any head count loads the XCDs equally; fewer than 16 units: everything block by block)
+int64_t unit_grid(int64_t tiles, int blocks, int32_t &whole_slots) {
+    const int64_t units = tiles / blocks;
+    const int64_t ws = units >= 16 ? units / 8 * blocks : 0;
+    whole_slots = (int32_t)ws;
+    return 8 * (ws + (tiles - ws * 8 + 7) / 8);
 }
 
 template <typename T, int D, bool SOFTCAP, bool DROPOUT = false>
@@ -75,7 +78,7 @@ int run_bwd(fa::BParams bp, int rows_q_max, int rows_k_max, hipStream_t stream) 
         if (tiles > 0x7fffffff) return FA_ERR_BAD_SHAPE;
         if (tiles > 0) {
             bp.num_tiles = (int32_t)tiles;
-            const int64_t grid = unit_grid(tiles, bp.num_blocks);
+            const int64_t grid = unit_grid(tiles, bp.num_blocks, bp.whole_slots);
             if (grid > 0x7fffffff) return FA_ERR_BAD_SHAPE;
             bp.grid = (int32_t)grid;
             const int st = one_block ? launch_kernel(fa::bwd_dkdv_kernel<T, D, 1, SOFTCAP, DROPOUT>, fa::smem_bytes_dkdv<D>(), attr1, bp.grid, 256, bp, stream)
@@ -91,7 +94,7 @@ int run_bwd(fa::BParams bp, int rows_q_max, int rows_k_max, hipStream_t stream) 
         if (tiles > 0x7fffffff) return FA_ERR_BAD_SHAPE;
         if (tiles > 0) {
             bp.num_tiles = (int32_t)tiles;
-            const int64_t grid = unit_grid(tiles, bp.num_blocks);
+            const int64_t grid = unit_grid(tiles, bp.num_blocks, bp.whole_slots);
             if (grid > 0x7fffffff) return FA_ERR_BAD_SHAPE;
             bp.grid = (int32_t)grid;
             const int st = launch_kernel(fa::bwd_dq_kernel<T, D, NBQ, SOFTCAP, DROPOUT>, fa::smem_bytes_dq<D>(), attr, bp.grid, 256, bp, stream);

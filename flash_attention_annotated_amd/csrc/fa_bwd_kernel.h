@@ -93,7 +93,8 @@ struct BParams {
     int32_t h_ratio;
     int32_t num_blocks;    // blocks per (batch, head): key blocks (dK/dV) or query blocks (dQ)
     int32_t num_tiles;     // work list length
-    int32_t grid;          // workgroups launched (multiple of 8 units, see decode_block)
+    int32_t whole_slots;   // workgroup slots per XCD dealt as whole (batch, head) units; the slots behind them block by block
+    int32_t grid;          // workgroups launched (a multiple of 8, see decode_block)
     int32_t window_left, window_right;
     float scale_log2;      // log2(e) * (softmax_scale, or the softcap value under softcap)
     float softcap_pre;     // softmax_scale / softcap (0 when softcap is off)
@@ -107,12 +108,12 @@ struct BParams {
 };
 
 // Work list (batch, head, block) cut into units = all blocks of one (batch, head) (they stream the same operands);
-// units are dealt round-robin to the 8 XCDs exactly like decode_tile() does for the forward.
+// units are dealt round-robin to the 8 XCDs exactly like tile_of_wg() does for the forward: whole units as far as they
+// deal evenly (whole_slots), the remaining heads block by block.
 __device__ __forceinline__ bool decode_block(const BParams &p, int &block, int &head, int &batch, int heads) {
     const int wg = blockIdx.x;
     const int xcd = wg & 7, slot = wg >> 3;
-    const int unit = (slot / p.num_blocks) * 8 + xcd;
-    const int tile = unit * p.num_blocks + slot % p.num_blocks;
+    const int tile = slot < p.whole_slots ? ((slot / p.num_blocks) * 8 + xcd) * p.num_blocks + slot % p.num_blocks : slot * 8 + xcd;
     if (tile >= p.num_tiles) return false;
     const int bh = tile / p.num_blocks;
     block = p.num_blocks - 1 - tile % p.num_blocks;

@@ -46,3 +46,20 @@ def test_every_tile_once_and_xcds_balanced(b, h_k, h_ratio, m):
             xcd_of[t] = wg & 7
     for t0 in range(0, tiles, h_ratio):
         assert len({xcd_of[t] for t in range(t0, t0 + h_ratio)}) == 1
+
+
+@pytest.mark.parametrize("units,blocks", [(1, 1), (20, 64), (42, 32), (12, 7), (64, 32), (17, 5), (40, 3), (16, 9)])
+def test_backward_block_map(units, blocks):
+    """decode_block() of the backward kernels (csrc/fa_bwd_kernel.h) with unit_grid() (csrc/fa_bwd_api.hip)."""
+    tiles = units * blocks
+    ws = units // 8 * blocks if units >= 16 else 0
+    grid = 8 * (ws + (tiles - ws * 8 + 7) // 8)
+    seen, per_xcd = [], [0] * 8
+    for wg in range(grid):
+        xcd, slot = wg & 7, wg >> 3
+        t = ((slot // blocks) * 8 + xcd) * blocks + slot % blocks if slot < ws else slot * 8 + xcd
+        if t < tiles:
+            seen.append(t)
+            per_xcd[xcd] += 1
+    assert sorted(seen) == list(range(tiles))
+    assert max(per_xcd) - min(per_xcd) <= 1
