@@ -344,11 +344,7 @@ __device__ __forceinline__ void drain_scores(f32x16 &s0, f32x16 &s1) {
 #ifndef FA_ABLATE
 #define FA_ABLATE 0
 #endif
-// developer-only (the open sliding-window / MASKED-block question, see mask_ok): 1 = MASKED block also under a left window,
-// 2 = ... without the l_a restore, 4 = ... one tile later
-#ifndef FA_WINMASK
-#define FA_WINMASK 0
-#endif
+
 
 // Developer-only phase timestamps (never shipped: -DFA_TIMING builds, tools/wg_phases.py): every wave drops the 100 MHz
 // wall clock into 64 spare LDS bytes (per wave) behind the K/V rings (LDS traffic only: the loop's manual vmcnt accounting is not
@@ -1007,10 +1003,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     fast_last = __builtin_amdgcn_readfirstlane(fast_last);
     fast_first = __builtin_amdgcn_readfirstlane(fast_first);
     // masks the generated block can apply itself: sequence end, causal / right window (no ALiBi or softcap)
-    // (the MASKED block stays off under a left window: with it, a rare data-dependent case -- 2 of 24 (seed, head) cases of
-    //  tests/test_flash_attn_gpu.py::test_sliding_window_seeds -- lost one half-step's row sum on the rows whose first visible
-    //  half-step is partly masked; not understood yet, the diagonal tiles of a sliding window therefore take the generic path)
-    const bool mask_ok = !SOFTCAP && jend > 0 && !p.alibi && (p.window_left < 0 || (FA_WINMASK & 1));
+    const bool mask_ok = !SOFTCAP && jend > 0 && !p.alibi;
     auto from_ok = [&](int jt) { return jt + 1 >= fast_first; };  // the scores a block starting at jt computes are S(jt + 1) ...
 
     // Driver.  ONE call site of generic_half (its body is large; inlining it twice wrecks register allocation).
@@ -1100,7 +1093,12 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
                 if (count != 0) {  // a guard tripped: the next half-step is the generic path's
                     tripped = true;
                     if (done & 1) to_canonical_after_odd();
-                } else if (restore_la) {  // the block's last half-step formed a phantom P_A: only l_a saw it
+                }
+                // The block's last half-step formed a phantom P_A (scores of a half-step this wave does not need: zeros behind a
+                // mask, but REAL keys behind an unmasked last tile or behind the end of a split-KV range): only l_a saw it.
+                // Also when that very half-step tripped guard A -- the generic path has nothing left to redo (j >= jend) and
+                // would keep the phantom's row sums (found under split-KV + sliding window: DESIGN.md 4.1b).
+                if (restore_la && j >= jend) {
                     l_a = l_a_saved;
                     redo_a = false;
                 }
@@ -1118,9 +1116,8 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
             // sequence that is not a multiple of 64 -- in the MASKED form of the block (the fresh scores get the mask, two
             // VALU instructions per score, before anything reads them).  Whole tiles: a trailing half-step the wave does not
             // need is fully masked and contributes exact zeros; the last half-step's P_A is a phantom as above.
-            if (addr32 && mask_ok && from_ok((FA_WINMASK & 4) && p.window_left >= 0 ? j - 2 : j) && !tripped && (j & 1) == 0 && j < jend &&
-                !(FA_ABLATE & 128))
-                run_block(std::true_type{}, (jend + 1 - j) >> 1, !((FA_WINMASK & 2) && p.window_left >= 0));
+            if (addr32 && mask_ok && from_ok(j) && !tripped && (j & 1) == 0 && j < jend && !(FA_ABLATE & 128))
+                run_block(std::true_type{}, (jend + 1 - j) >> 1, true);
         }
         // fast: up to three tiles (one turn of the LDS rings) per iteration; the first turn starts at the ring slot of
         // tile j/2 (`skip` slots are already behind us); every fast tile issues 2 LD_PER_THREAD LDS-DMA pieces, one per
