@@ -258,7 +258,7 @@ int effective_variant(const fa_fwd_params *p) {
 
 struct SplitPlan {
     int splits;
-    int64_t o_bytes, lse_bytes, total;  // partial O (16-bit, (splits, b, sq, h, d)) and LSE (fp32, (splits, b, h, sq))
+    int64_t o_bytes, lse_bytes, total;  // partial O (fp32, (splits, b, sq, h, d)) and LSE (fp32, (splits, b, h, sq))
 };
 SplitPlan split_plan(const fa_fwd_params *p, int variant) {
     SplitPlan sp{1, 0, 0, 0};
@@ -281,7 +281,7 @@ SplitPlan split_plan(const fa_fwd_params *p, int variant) {
     if (n <= 1) return sp;
     sp.splits = n;
     const int64_t rows = (int64_t)p->b * p->seqlen_q;
-    sp.o_bytes = (n * rows * p->h * p->d * 2 + 255) & ~int64_t(255);
+    sp.o_bytes = (n * rows * p->h * p->d * 4 + 255) & ~int64_t(255);
     sp.lse_bytes = (n * rows * p->h * 4 + 255) & ~int64_t(255);
     sp.total = sp.o_bytes + sp.lse_bytes;
     return sp;
@@ -290,7 +290,7 @@ SplitPlan split_plan(const fa_fwd_params *p, int variant) {
 // ---- split-KV merge: out = sum_s w_s O_s / sum_s w_s, w_s = exp(lse_s - max lse); lse = max + log sum w.  One thread =
 // one 16-byte chunk of one (batch, row, head); splits with LSE = +inf (no key in their range) carry no weight.
 template <typename T>
-__global__ void combine_splits_kernel(const T *__restrict__ o_acc, const float *__restrict__ lse_acc, T *__restrict__ out,
+__global__ void combine_splits_kernel(const float *__restrict__ o_acc, const float *__restrict__ lse_acc, T *__restrict__ out,
                                       float *__restrict__ lse_out, int splits, int b, int sq, int h, int d,
                                       int64_t o_bs, int64_t o_rs, int64_t o_hs) {
     const int chunks = d >> 3;
@@ -317,8 +317,9 @@ __global__ void combine_splits_kernel(const T *__restrict__ o_acc, const float *
                 if (l == INFINITY) continue;
                 const float w = __expf(l - mx);
                 wsum += w;
-                float x[8];
-                unpack8<T>(*reinterpret_cast<const uint4 *>(o_acc + s * o_split + (((int64_t)bb * sq + row) * h + hd) * d + c * 8), x);
+                const float4 *src = reinterpret_cast<const float4 *>(o_acc + s * o_split + (((int64_t)bb * sq + row) * h + hd) * d + c * 8);
+                const float4 x0 = src[0], x1 = src[1];
+                const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc[j] += w * x[j];
             }
@@ -849,12 +850,12 @@ int fa_fwd(const fa_fwd_params *p, void *stream_) {
     const int64_t total = (int64_t)p->b * p->seqlen_q * p->h * (p->d / 8);
     const int blocks = (int)std::min<int64_t>((total + 255) / 256, 256 * 8);
     if (bf16)
-        hipLaunchKernelGGL(combine_splits_kernel<__bf16>, dim3(blocks), dim3(256), 0, stream, static_cast<const __bf16 *>(kp.o),
+        hipLaunchKernelGGL(combine_splits_kernel<__bf16>, dim3(blocks), dim3(256), 0, stream, static_cast<const float *>(kp.o),
                            kp.lse, static_cast<__bf16 *>(p->o), p->softmax_lse, sp.splits, p->b, p->seqlen_q, p->h, p->d,
                            p->o_batch_stride, p->o_row_stride, p->o_head_stride);
     else
         hipLaunchKernelGGL(combine_splits_kernel<_Float16>, dim3(blocks), dim3(256), 0, stream,
-                           static_cast<const _Float16 *>(kp.o), kp.lse, static_cast<_Float16 *>(p->o), p->softmax_lse,
+                           static_cast<const float *>(kp.o), kp.lse, static_cast<_Float16 *>(p->o), p->softmax_lse,
                            sp.splits, p->b, p->seqlen_q, p->h, p->d, p->o_batch_stride, p->o_row_stride, p->o_head_stride);
     if (hipGetLastError() != hipSuccess) return FA_ERR_LAUNCH;
     return FA_OK;

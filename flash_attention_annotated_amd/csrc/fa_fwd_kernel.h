@@ -613,6 +613,22 @@ __global__ __launch_bounds__(NWAVES * 64, (D <= 128 ? 2 : 1)) void fwd_kernel(co
             // csrc/flash_attn/src/softmax.h:178-180: +inf for rows with no valid key
             p.lse[lse_base + my_row] = empty ? INFINITY : m_run * sc.scale + __logf(l_tot);
         }
+        if (p.num_splits > 1) {
+            // split-KV partial: fp32 in the caller's workspace (role of out_accum, csrc/flash_attn/flash_api.cpp:297-318), straight
+            // from the accumulators -- 4 consecutive head dims = one 16-byte store per lane; the merge launch rounds once
+            float *opf = (float *)p.o + o_base + (int64_t)head * p.o_head_stride + (int64_t)my_row * p.o_row_stride;
+            if (my_row < sq) {
+#pragma unroll
+                for (int db = 0; db < DBLOCKS; ++db)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const int col = db * 32 + 8 * g4 + 4 * hh;
+                        if (col < p.d)
+                            *(float4 *)(opf + col) = make_float4(o_acc[db][4 * g4] * inv, o_acc[db][4 * g4 + 1] * inv,
+                                                                 o_acc[db][4 * g4 + 2] * inv, o_acc[db][4 * g4 + 3] * inv);
+                    }
+            }
+        } else {
         char *obuf = smem + wave * (32 * O_ROW_BYTES);
 #pragma unroll
         for (int db = 0; db < DBLOCKS; ++db)
@@ -623,7 +639,9 @@ __global__ __launch_bounds__(NWAVES * 64, (D <= 128 ? 2 : 1)) void fwd_kernel(co
                 w[1] = Elem<T>::pack2(o_acc[db][4 * g4 + 2] * inv, o_acc[db][4 * g4 + 3] * inv);
                 *(u32x2 *)(obuf + r * O_ROW_BYTES + (db * 32 + 8 * g4 + 4 * hh) * 2) = w;
             }
+        }
     }
+    if (p.num_splits > 1) return;  // (uniform over the launch: no wave is left waiting at the barrier below)
     __syncthreads();
     if (wave_active) {
         const char *obuf = smem + wave * (32 * O_ROW_BYTES);

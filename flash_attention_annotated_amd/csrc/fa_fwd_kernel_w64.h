@@ -1241,6 +1241,25 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
             if (row_a_e < sq) p.lse[lse_base + row_a_e] = e_a ? INFINITY : m_a * scale_e + __logf(lt_a);
             if (row_b_e < sq) p.lse[lse_base + row_b_e] = e_b ? INFINITY : m_b * scale_e + __logf(lt_b);
         }
+        if (p.num_splits > 1) {
+            // split-KV partial: fp32 in the caller's workspace (role of out_accum, csrc/flash_attn/flash_api.cpp:297-318), straight
+            // from the accumulators -- 4 consecutive head dims = one 16-byte store per lane; the merge launch rounds once
+            float *opf = (float *)p.o + o_base + (int64_t)head * p.o_head_stride;
+#pragma unroll
+            for (int db = 0; db < DBLOCKS; ++db)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int col = db * 32 + 8 * g4 + 4 * hh_e;
+                    if (col < p.d) {
+                        if (row_a_e < sq)
+                            *(float4 *)(opf + (int64_t)row_a_e * p.o_row_stride + col) =
+                                make_float4(oa[db][4 * g4] * inv_a, oa[db][4 * g4 + 1] * inv_a, oa[db][4 * g4 + 2] * inv_a, oa[db][4 * g4 + 3] * inv_a);
+                        if (row_b_e < sq)
+                            *(float4 *)(opf + (int64_t)row_b_e * p.o_row_stride + col) =
+                                make_float4(ob[db][4 * g4] * inv_b, ob[db][4 * g4 + 1] * inv_b, ob[db][4 * g4 + 2] * inv_b, ob[db][4 * g4 + 3] * inv_b);
+                    }
+                }
+        } else {
         char *obuf = smem + wave * (64 * O_ROW_BYTES);
 #pragma unroll
         for (int db = 0; db < DBLOCKS; ++db)
@@ -1255,10 +1274,11 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
                 *(u32x2 *)(obuf + r_e * O_ROW_BYTES + col) = wa;
                 *(u32x2 *)(obuf + (32 + r_e) * O_ROW_BYTES + col) = wb;
             }
+        }
     }
     // (no workgroup barrier: a wave reads back only its own 64 staged rows, and LDS operations of one wave are in order)
     FA_STAMP(52);  // O normalised and in LDS
-    if (wave_active) {
+    if (wave_active && p.num_splits <= 1) {
         const char *obuf = smem + wave * (64 * O_ROW_BYTES);
         // (LDS reads outside the predicate: all of them are issued before the first store; inside it each read is
         //  waited for in its own exec-masked block -- 16 serial LDS round trips at D = 128)

@@ -151,7 +151,8 @@ typedef struct fa_fwd_params {
     /* Split-KV (set_params_splitkv / num_splits_heuristic csrc/flash_attn/flash_api.cpp:257-329, combine kernel
      * src/flash_fwd_kernel.h:1108-1290): 1 = off, N > 1 = the key range of every tile is cut into N parts computed by
      * N workgroups and merged by a second launch, 0 = library heuristic (splits only dense problems with few tiles,
-     * i.e. decode).  Needs params->workspace of fa_fwd_workspace_size() bytes when the effective value is > 1.
+     * i.e. decode).  Needs params->workspace of fa_fwd_workspace_size() bytes when the effective value is > 1 (the partial
+     * outputs and LSEs of the parts, both fp32 like the reference's out_accum / softmax_lse_accum).
      * The default-initialised struct (0) therefore may split: callers without a workspace must pass 1. */
     int32_t num_splits;
 
