@@ -249,7 +249,9 @@ int effective_variant(const fa_fwd_params *p) {
             const int tile = head_dim_tile(p->d);
             // (round 2: at head-dim tile 128 the generated loop applies the causal mask itself -- the diagonal tiles no longer
             //  run the generic half-step -- and the 256-row kernel wins from seqlen 512 on: causal s512 / s1024 308 / 379
-            //  (8 waves x 32 rows) -> 319 / 485 TFLOP/s; the d64 kernel has no generated loop yet and keeps the rule)
+            //  (8 waves x 32 rows) -> 319 / 485 TFLOP/s.  Head-dim tile 64 has its generated loop too (FastLoop64), but with twice
+            //  the VALU per MFMA the 4-wave x 32-row shape still wins on short key ranges: causal s512 / 1024 / 2048 278 / 394 / 518
+            //  against 227 / 331 / 497, non-causal s512 490 against 443 (profiles/r2_fwd_grid.txt): the rule stays)
             if (tile == 64 && ((causal_like && p->seqlen_k <= 2048) || p->seqlen_k <= 512)) variant = 2;
         }
     }
