@@ -81,8 +81,16 @@ int run_bwd(fa::BParams bp, int rows_q_max, int rows_k_max, hipStream_t stream) 
             const int64_t grid = unit_grid(tiles, bp.num_blocks, bp.whole_slots);
             if (grid > 0x7fffffff) return FA_ERR_BAD_SHAPE;
             bp.grid = (int32_t)grid;
-            const int st = one_block ? launch_kernel(fa::bwd_dkdv_kernel<T, D, 1, SOFTCAP, DROPOUT>, fa::smem_bytes_dkdv<D>(), attr1, bp.grid, 256, bp, stream)
-                                     : launch_kernel(fa::bwd_dkdv_kernel<T, D, NBK2, SOFTCAP, DROPOUT>, fa::smem_bytes_dkdv<D>(), attr, bp.grid, 256, bp, stream);
+            int st;
+            if constexpr (D == 128 && !SOFTCAP && !DROPOUT) {
+                // head dims <= 96 on the 128-wide tiles: the instantiation whose generated loop skips the zero padding
+                static std::atomic<uint64_t> attr96{0};
+                st = bp.d <= 96 ? launch_kernel(fa::bwd_dkdv_kernel<T, D, 1, false, false, 96>, fa::smem_bytes_dkdv<D>(), attr96, bp.grid, 256, bp, stream)
+                                : launch_kernel(fa::bwd_dkdv_kernel<T, D, 1, false, false>, fa::smem_bytes_dkdv<D>(), attr, bp.grid, 256, bp, stream);
+            } else {
+                st = one_block ? launch_kernel(fa::bwd_dkdv_kernel<T, D, 1, SOFTCAP, DROPOUT>, fa::smem_bytes_dkdv<D>(), attr1, bp.grid, 256, bp, stream)
+                               : launch_kernel(fa::bwd_dkdv_kernel<T, D, NBK2, SOFTCAP, DROPOUT>, fa::smem_bytes_dkdv<D>(), attr, bp.grid, 256, bp, stream);
+            }
             if (st != FA_OK) return st;
         }
     }
@@ -97,7 +105,14 @@ int run_bwd(fa::BParams bp, int rows_q_max, int rows_k_max, hipStream_t stream) 
             const int64_t grid = unit_grid(tiles, bp.num_blocks, bp.whole_slots);
             if (grid > 0x7fffffff) return FA_ERR_BAD_SHAPE;
             bp.grid = (int32_t)grid;
-            const int st = launch_kernel(fa::bwd_dq_kernel<T, D, NBQ, SOFTCAP, DROPOUT>, fa::smem_bytes_dq<D>(), attr, bp.grid, 256, bp, stream);
+            int st;
+            if constexpr (D == 128 && !SOFTCAP && !DROPOUT) {
+                static std::atomic<uint64_t> attr96{0};
+                st = bp.d <= 96 ? launch_kernel(fa::bwd_dq_kernel<T, D, NBQ, false, false, 96>, fa::smem_bytes_dq<D>(), attr96, bp.grid, 256, bp, stream)
+                                : launch_kernel(fa::bwd_dq_kernel<T, D, NBQ, false, false>, fa::smem_bytes_dq<D>(), attr, bp.grid, 256, bp, stream);
+            } else {
+                st = launch_kernel(fa::bwd_dq_kernel<T, D, NBQ, SOFTCAP, DROPOUT>, fa::smem_bytes_dq<D>(), attr, bp.grid, 256, bp, stream);
+            }
             if (st != FA_OK) return st;
         }
     }

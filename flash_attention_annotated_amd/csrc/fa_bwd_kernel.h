@@ -38,21 +38,23 @@ namespace fa {
 
 // Score-tile MFMAs whose B operand stays in arch VGPRs (used where the AGPR half is full of accumulators);
 // Mfma<T>::s_first / s_acc take B from AGPRs.  hipcc pads no hazards around these: callers drain before VALU reads.
+// (s_nop 1 in front: the B operand may have been copied out of an AGPR by a VALU instruction right before, and hipcc pads
+//  nothing for asm MFMAs)
 template <typename T> struct BMfma;
 template <> struct BMfma<__bf16> {
     static __device__ __forceinline__ void s_first_v(f32x16 &d, u32x4 a, u32x4 b) {
-        asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b));
+        asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b));
     }
     static __device__ __forceinline__ void s_acc_v(f32x16 &d, u32x4 a, u32x4 b) {
-        asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
+        asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
     }
 };
 template <> struct BMfma<_Float16> {
     static __device__ __forceinline__ void s_first_v(f32x16 &d, u32x4 a, u32x4 b) {
-        asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b));
+        asm("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b));
     }
     static __device__ __forceinline__ void s_acc_v(f32x16 &d, u32x4 a, u32x4 b) {
-        asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
+        asm("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
     }
 };
 // asm MFMA results -> VALU readers: 11+ wait states, with the tiles as operands so nothing is scheduled across
@@ -69,6 +71,8 @@ __device__ __forceinline__ void drain_acc(f32x16 (&a)[N]) {
     else asm volatile("s_nop 15\n\ts_nop 7" : "+a"(a[0]), "+a"(a[1]), "+a"(a[2]), "+a"(a[3]), "+a"(a[4]), "+a"(a[5]),
                       "+a"(a[6]), "+a"(a[7]));
 }
+
+template <typename L> struct LoopTag { using type = L; };  // (C++17: no std::type_identity)
 
 #ifndef FA_BWD_ABLATE
 #define FA_BWD_ABLATE 0  // developer-only: 1 = no generated asm block in bwd_dkdv_kernel
@@ -256,7 +260,7 @@ __device__ __forceinline__ void bwd_point(const BParams &p, float x, float dp, f
 // dK / dV.  NB = 32-key blocks per wave: every Q / dO / Q^T / dO^T fragment read from LDS feeds NB MFMAs (the
 // one-block form moves 1 KiB of LDS per MFMA, which is the LDS bandwidth limit of the CU).
 // ------------------------------------------------------------------------------------------------------------------
-template <typename T, int D, int NB, bool SOFTCAP, bool DROPOUT = false>
+template <typename T, int D, int NB, bool SOFTCAP, bool DROPOUT = false, int DEFF = D>
 __global__ __launch_bounds__(256, 1) void bwd_dkdv_kernel(const BParams p) {
     constexpr int NT = 256;
     constexpr int WKEYS = 32 * NB;             // keys per wave
@@ -491,12 +495,20 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_kernel(const BParams p) {
                 }
                 const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
                 const uint32_t stat0 = lds0 + 4 * TILE_BYTES;
-                using Loop = std::conditional_t<D == 128, BwdLoop128<T>, BwdLoop64<T>>;
-                Loop::run(dk_acc, dv_acc, kf[0], vf[0], (uint32_t)kbase, (uint32_t)vbase, qoffb, goffb,
+                auto run_loop = [&](auto tag) {   // (DEFF = 96: head dims <= 96 on the 128-wide tiles, the form that skips the zero padding)
+                    using Loop = typename decltype(tag)::type;
+                    Loop::run(dk_acc, dv_acc, kf[0], vf[0], (uint32_t)kbase, (uint32_t)vbase, qoffb, goffb,
                                    stat0 + 16 * hh, (uint32_t)lane * 4u, stat0 + (odd ? 2 * BM * 4 : 0) + lane * 4, p.scale_log2,
                                    odd ? 1.f : LOG2E, qdesc, gdesc, sdesc, (uint32_t)((row0 + BM) * q_rs * 2),
                                    (uint32_t)((row0 + BM) * g_rs * 2), (uint32_t)((row0 + BM) * 4), (uint32_t)(BM * q_rs * 2),
                                    (uint32_t)(BM * g_rs * 2), lds0, lds_wave, cur, count);
+                };
+                if constexpr (D == 128) {
+                    if constexpr (DEFF == 96) run_loop(LoopTag<BwdLoop96<T>>{});
+                    else run_loop(LoopTag<BwdLoop128<T>>{});
+                } else {
+                    run_loop(LoopTag<BwdLoop64<T>>{});
+                }
                 it += count - 1;  // tile it + count is in LDS, its barrier passed
                 continue;
             }
@@ -694,7 +706,7 @@ template <int D> constexpr int dq_nbuf() { return D <= 128 ? 3 : 2; }  // K / V 
 // ------------------------------------------------------------------------------------------------------------------
 // dQ.  NB = 32-row query blocks per wave (K / V / K^T fragments from LDS feed NB MFMAs each).
 // ------------------------------------------------------------------------------------------------------------------
-template <typename T, int D, int NB, bool SOFTCAP, bool DROPOUT = false>
+template <typename T, int D, int NB, bool SOFTCAP, bool DROPOUT = false, int DEFF = D>
 __global__ __launch_bounds__(256, 1) void bwd_dq_kernel(const BParams p) {
     constexpr int NT = 256;
     constexpr int WROWS = 32 * NB;
@@ -893,11 +905,16 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_kernel(const BParams p) {
                     voffb[i] = v_off[i] - 1024u * i;
                 }
                 const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
-                using Loop = std::conditional_t<D == 128, BwdDqLoop128<T>, BwdDqLoop64<T>>;
-                Loop::run(dq_acc, qf[0], qf[1], gf[0], gf[1], lse2[0], lse2[1], dsum[0], dsum[1], (uint32_t)kbase,
-                                     (uint32_t)vbase, koffb, voffb, p.scale_log2, kdesc, vdesc,
-                                     (uint32_t)((n + 1) * BLOCK_N * k_rs * 2), (uint32_t)((n + 1) * BLOCK_N * v_rs * 2),
-                                     (uint32_t)(BLOCK_N * k_rs * 2), (uint32_t)(BLOCK_N * v_rs * 2), lds0, lds_wave, cur, count);
+                // (no lambda around the call: all 256 AGPRs are operands of the block, and hipcc shuffles them through scratch when
+                //  the arrays reach the asm statement through a closure.  DEFF = 96: head dims <= 96 on the 128-wide tiles)
+#define FA_DQ_LOOP_ARGS dq_acc, qf[0], qf[1], gf[0], gf[1], lse2[0], lse2[1], dsum[0], dsum[1], (uint32_t)kbase, \
+                                     (uint32_t)vbase, koffb, voffb, p.scale_log2, kdesc, vdesc, \
+                                     (uint32_t)((n + 1) * BLOCK_N * k_rs * 2), (uint32_t)((n + 1) * BLOCK_N * v_rs * 2), \
+                                     (uint32_t)(BLOCK_N * k_rs * 2), (uint32_t)(BLOCK_N * v_rs * 2), lds0, lds_wave, cur, count
+                if constexpr (D == 64) BwdDqLoop64<T>::run(FA_DQ_LOOP_ARGS);
+                else if constexpr (DEFF == 96) BwdDqLoop96<T>::run(FA_DQ_LOOP_ARGS);
+                else BwdDqLoop128<T>::run(FA_DQ_LOOP_ARGS);
+#undef FA_DQ_LOOP_ARGS
                 n += count - 1;  // tile n + count is in LDS, its barrier passed
                 continue;
             }

@@ -56,7 +56,8 @@ def test_no_unpadded_mfma_or_trans_hazards(tmp_path, unit):
             # unrolled tile
             body = "\n".join(lines)
             blk = body[body.index(".Lfb_t1_"):body.rindex(".Lfb_exit_")]
-            per_tile = 64 if "Li128E" in name else 32   # MFMAs per tile and wave (head dim 128 / 64), two unrolled tiles
+            # MFMAs per tile and wave (head dim 128 / 96 on the 128-wide tiles / 64), two unrolled tiles
+            per_tile = 32 if "Li64ELi1E" in name else (48 if name.endswith("Li96EEEvNS_7BParamsE") else 64)
             assert "scratch_" not in blk and blk.count("v_mfma") == 2 * per_tile, name
             assert any_scratch <= 24, (name, any_scratch)
         elif "bwd_dq_kernel" in name and ".Ldq_exit_" in "\n".join(lines):
@@ -65,7 +66,8 @@ def test_no_unpadded_mfma_or_trans_hazards(tmp_path, unit):
             body = "\n".join(lines)
             blk = body[body.index(".Ldq_p1_"):body.rindex(".Ldq_exit_")]
             assert "scratch_" not in blk, name
-            u = 16 if "Li128E" in name else 8           # MFMAs of one dQ group (head dim 128 / 64)
+            # MFMAs of one dQ group (head dim 128 / 96 on the 128-wide tiles / 64)
+            u = 8 if "Li64ELi2E" in name else (12 if name.endswith("Li96EEEvNS_7BParamsE") else 16)
             assert blk.count("v_mfma") == 3 * 2 * u + 3 * 6 * u + 3 * u, (name, blk.count("v_mfma"))
             assert any_scratch <= 64, (name, any_scratch)
         elif "bwd_" in name and "Li256E" not in name:

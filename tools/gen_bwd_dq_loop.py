@@ -144,17 +144,33 @@ def group_sdp(E, slot, kb, uid, valu_kb, dma_slot, nxt):
             E.e(f"s_add_u32 m0, %[lds_wave], {VREG + dma_slot * TILE}")
         E.wait_for(("k", uid, ks))
         c = (lambda r: "0" if ks == 0 else v(r, 16))
-        E.e(f"{mf} {v(s0, 16)}, {v(KR + 4 * (ks % 3), 4)}, %[qa{ks}], {c(s0)}")
+        # LDS-DMA pieces of the next tile: K pieces behind the first MFMA of the first LD k-steps, V pieces behind the following
+        # k-steps (one per k-step when there are 2 LD of them, otherwise also behind the third MFMA)
+        first, third = [], []
         if dma_slot is not None:
             if ks < LD:
-                E.e(f"buffer_load_dwordx4 {v(KOFF + ks)}, %[kdesc], %[ktile] offen offset:{1024 * ks} lds")
+                first = [("k", ks)]
+            elif KSTEPS >= 2 * LD:
+                first = [("v", ks - LD)]
             else:
-                E.e(f"buffer_load_dwordx4 {v(VOFF + ks - LD)}, %[vdesc], %[vtile] offen offset:{1024 * (ks - LD)} lds")
+                per = -(-LD // (KSTEPS - LD))
+                vp = list(range((ks - LD) * per, min(LD, (ks - LD + 1) * per)))
+                first, third = [("v", i) for i in vp[:1]], [("v", i) for i in vp[1:]]
+
+        def pieces(lst):
+            for kind, i in lst:
+                if kind == "k":
+                    E.e(f"buffer_load_dwordx4 {v(KOFF + i)}, %[kdesc], %[ktile] offen offset:{1024 * i} lds")
+                else:
+                    E.e(f"buffer_load_dwordx4 {v(VOFF + i)}, %[vdesc], %[vtile] offen offset:{1024 * i} lds")
+        E.e(f"{mf} {v(s0, 16)}, {v(KR + 4 * (ks % 3), 4)}, %[qa{ks}], {c(s0)}")
+        pieces(first)
         sl.slot(4 * ks)
         E.e(f"{mf} {v(s1, 16)}, {v(KR + 4 * (ks % 3), 4)}, %[qb{ks}], {c(s1)}")
         sl.slot(4 * ks + 1)
         E.wait_for(("v", uid, ks))
         E.e(f"{mf} {v(d0, 16)}, {v(VR + 4 * (ks % 3), 4)}, %[ga{ks}], {c(d0)}")
+        pieces(third)
         sl.slot(4 * ks + 2)
         E.e(f"{mf} {v(d1, 16)}, {v(VR + 4 * (ks % 3), 4)}, %[gb{ks}], {c(d1)}")
         sl.slot(4 * ks + 3)
@@ -279,6 +295,7 @@ HEADER = '''// GENERATED by tools/gen_bwd_dq_loop.py -- do not edit; regenerate 
 namespace fa {
 
 template <typename T> struct BwdDqLoop128;
+template <typename T> struct BwdDqLoop96;   // head dims 65..96 on the 128-wide tiles: the zero padding is skipped (6 k-steps, 3 dQ blocks per row block)
 template <typename T> struct BwdDqLoop64;   // head dim 64: LDS rows of 128 B, 4 k-steps, 2 dQ blocks per row block, 2 LDS-DMA pieces per wave
 '''
 
@@ -305,9 +322,9 @@ FUNC = '''template <> struct BwdDqLoop%(D)d<%(T)s> {
 '''
 
 
-def operands(nacc, nks, ld):
+def operands(ndb_tile, ndb, nks, ld):
     join = lambda xs: (",\n              ".join(", ".join(xs[i:i + 4]) for i in range(0, len(xs), 4)))
-    accs = [f'[dq{i}] "+a"(dq[{i}])' for i in range(nacc)]
+    accs = [f'[dq{nb * ndb_tile + db}] "+a"(dq[{nb * ndb_tile + db}])' for nb in range(2) for db in range(ndb)]
     frags = [f'[{n}{i}] "a"({n}[{i}])' for n in ("qa", "qb", "ga", "gb") for i in range(nks)]
     offs = [f'"{{v{KOFF + i}}}"(koff[{i}])' for i in range(ld)] + [f'"{{v{VOFF + i}}}"(voff[{i}])' for i in range(ld)]
     return join(accs), join(frags), join(offs)
@@ -325,14 +342,14 @@ def main():
     path = os.path.join(root, "flash_attention_annotated_amd", "csrc", "fa_bwd_dq_loop_gen.h")
     global D, ROWB, TILE, VREG, KSTEPS, NSTEP, LD
     text = HEADER
-    for d in (128, 64):
-        D, ROWB, TILE, KSTEPS, NSTEP, LD = d, d * 2, 64 * d * 2, d // 16, 2 * (d // 32), d // 32
+    for d, deff in ((128, 128), (128, 96), (64, 64)):   # (head-dim tile, head dims contracted / produced)
+        D, ROWB, TILE, KSTEPS, NSTEP, LD = d, d * 2, 64 * d * 2, deff // 16, 2 * (deff // 32), d // 32
         VREG = NSLOT * TILE
         unused = [KOFF + i for i in range(LD, 4)] + [VOFF + i for i in range(LD, 4)]  # (no inputs there at LD = 2)
         clob = "".join(f', "v{i}"' for i in list(range(212)) + unused + list(range(RV, NVGPR)))
-        accs, frags, offs = operands(2 * (d // 32), KSTEPS, LD)
+        accs, frags, offs = operands(d // 32, deff // 32, KSTEPS, LD)
         for T, mf, cvt in (("__bf16", "v_mfma_f32_32x32x16_bf16", cvt_bf16), ("_Float16", "v_mfma_f32_32x32x16_f16", cvt_f16)):
-            text += "\n" + FUNC % {"T": T, "D": d, "NACC": 2 * (d // 32), "NKS": KSTEPS, "LD": LD, "accs": accs, "frags": frags,
+            text += "\n" + FUNC % {"T": T, "D": deff, "NACC": 2 * (d // 32), "NKS": d // 16, "LD": LD, "accs": accs, "frags": frags,
                                    "offs": offs, "body": render(gen_block(mf, cvt)), "clobbers": clob}
     text += "\n}  // namespace fa\n"
     if "--check" in sys.argv:

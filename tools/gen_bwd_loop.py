@@ -181,17 +181,33 @@ def group_sdp(E, c, rb, uid, valu, dma):
         E.wait_for(("q", uid, rb, ks))
         cs = "0" if ks == 0 else v(s, 16)
         cd = "0" if ks == 0 else v(dp, 16)
-        E.e(f"{mf} {v(s, 16)}, {v(QR + 4 * (pos % 3), 4)}, %[kf{ks}], {cs}")
+        # LDS-DMA pieces of the next tile: Q pieces behind the S MFMAs of the first LD k-steps, dO pieces behind the following
+        # MFMAs (one per k-step when there are 2 LD k-steps, otherwise also behind the dP MFMAs)
+        after_s, after_dp = [], []
         if dma:
-            if ks == 0:
-                E.e(f"buffer_load_dword {v(STATR)}, {v(SOFF)}, %[sdesc], %[stile] offen")
             if ks < LD:
-                E.e(f"buffer_load_dwordx4 {v(QOFF + ks)}, %[qdesc], %[qtile] offen offset:{1024 * ks} lds")
+                after_s = [("q", ks)]
+            elif KSTEPS >= 2 * LD:
+                after_s = [("g", ks - LD)]
             else:
-                E.e(f"buffer_load_dwordx4 {v(GOFF + ks - LD)}, %[gdesc], %[gtile] offen offset:{1024 * (ks - LD)} lds")
+                per = -(-LD // (KSTEPS - LD))      # dO pieces per remaining k-step
+                gp = list(range((ks - LD) * per, min(LD, (ks - LD + 1) * per)))
+                after_s, after_dp = [("g", i) for i in gp[:1]], [("g", i) for i in gp[1:]]
+
+        def pieces(lst):
+            for kind, i in lst:
+                if kind == "q":
+                    E.e(f"buffer_load_dwordx4 {v(QOFF + i)}, %[qdesc], %[qtile] offen offset:{1024 * i} lds")
+                else:
+                    E.e(f"buffer_load_dwordx4 {v(GOFF + i)}, %[gdesc], %[gtile] offen offset:{1024 * i} lds")
+        E.e(f"{mf} {v(s, 16)}, {v(QR + 4 * (pos % 3), 4)}, %[kf{ks}], {cs}")
+        if dma and ks == 0:
+            E.e(f"buffer_load_dword {v(STATR)}, {v(SOFF)}, %[sdesc], %[stile] offen")
+        pieces(after_s)
         sl.slot(2 * ks)
         E.wait_for(("g", uid, rb, ks))
         E.e(f"{mf} {v(dp, 16)}, {v(GR + 4 * (pos % 3), 4)}, %[vf{ks}], {cd}")
+        pieces(after_dp)
         sl.slot(2 * ks + 1)
     if dma:
         E.e("s_add_u32 %[qtile], %[qtile], %[qstep]")
@@ -304,6 +320,7 @@ HEADER = '''// GENERATED by tools/gen_bwd_loop.py -- do not edit; regenerate wit
 namespace fa {
 
 template <typename T> struct BwdLoop128;
+template <typename T> struct BwdLoop96;   // head dims 65..96 on the 128-wide tiles: the zero padding is skipped (6 k-steps, 3 blocks per accumulator)
 template <typename T> struct BwdLoop64;   // head dim 64: LDS rows of 128 B, 4 k-steps, 2 blocks per accumulator, 2 LDS-DMA pieces per wave
 '''
 
@@ -358,14 +375,14 @@ def main():
         path = sys.argv[sys.argv.index("--out") + 1]
     global D, ROWB, TILE, STAT, KSTEPS, NSTEP, LD
     text = HEADER
-    for d in (128, 64):
-        D, ROWB, TILE, KSTEPS, NSTEP, LD = d, d * 2, 64 * d * 2, d // 16, 2 * (d // 32), d // 32
+    for d, deff in ((128, 128), (128, 96), (64, 64)):   # (head-dim tile, head dims contracted / produced)
+        D, ROWB, TILE, KSTEPS, NSTEP, LD = d, d * 2, 64 * d * 2, deff // 16, 2 * (deff // 32), d // 32
         STAT = 4 * TILE
         inputs = set(range(QOFF, QOFF + LD)) | set(range(GOFF, GOFF + LD)) | {200, 202, 203, 208, 209}
         clob = "".join(f', "v{i}"' for i in range(NVGPR) if i not in inputs)
-        accs, frags, offs = operands(d // 32, KSTEPS, LD)
+        accs, frags, offs = operands(deff // 32, KSTEPS, LD)
         for T, mf, cvt in (("__bf16", "v_mfma_f32_32x32x16_bf16", cvt_bf16), ("_Float16", "v_mfma_f32_32x32x16_f16", cvt_f16)):
-            text += "\n" + FUNC % {"T": T, "D": d, "NDB": d // 32, "NKS": KSTEPS, "LD": LD, "accs": accs, "frags": frags, "offs": offs,
+            text += "\n" + FUNC % {"T": T, "D": deff, "NDB": d // 32, "NKS": d // 16, "LD": LD, "accs": accs, "frags": frags, "offs": offs,
                                    "body": render(gen_block(mf, cvt)), "clobbers": clob}
     text += "\n}  // namespace fa\n"
     if "--check" in sys.argv:
