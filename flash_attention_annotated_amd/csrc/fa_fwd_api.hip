@@ -219,6 +219,13 @@ bool fp8_native(const fa_fwd_params *p) {
     const void *ptrs[] = {p->q, p->k, p->v};
     for (const void *ptr : ptrs)
         if (reinterpret_cast<uintptr_t>(ptr) % 16 != 0) return false;
+    // The kernel addresses one (batch, kv head)'s K and V through raw buffer descriptors: 32-bit byte offsets (num_records,
+    // soffset = tile * row_stride) and int row strides.  A K or V of 2 GiB or more per batch entry has no safe path in the
+    // native kernel (its generic tile uses the same descriptors): those shapes take the expansion path, whose 16-bit kernels
+    // address with 64-bit tile bases.
+    const int64_t rows_k = p->cu_seqlens_q ? p->total_k : p->seqlen_k;
+    if (p->k_row_stride >= (int64_t(1) << 31) || p->v_row_stride >= (int64_t(1) << 31)) return false;
+    if (rows_k * p->k_row_stride >= (int64_t(1) << 31) || rows_k * p->v_row_stride >= (int64_t(1) << 31)) return false;
     return true;
 }
 
@@ -806,7 +813,8 @@ int fa_fwd(const fa_fwd_params *p, void *stream_) {
     kp.alibi_bs = (int32_t)p->alibi_slopes_batch_stride;
     kp.leftpad_k = p->leftpad_k;
     // dropout: keep iff randval <= floor(255 (1 - p)); 255 = everything kept = the branch is off
-    // (the reference's quantisation: p < 1/255 gives threshold 255 = nothing dropped, still scaled by 1 / (1 - p))
+    // (the 8-bit quantisation of the reference's ROCm back-end: any p > 0 gives a threshold <= 254, i.e. at least 1/256 of the
+    //  elements are dropped however small p is; the kept ones are scaled by 1 / (1 - p))
     kp.drop_thr = p->p_dropout > 0.f ? (int32_t)std::floor(255.0 * (1.0 - (double)p->p_dropout)) : 255;
     kp.rp_dropout = p->p_dropout > 0.f ? 1.f / (1.f - p->p_dropout) : 1.f;
     kp.rng_state = p->rng_state;

@@ -1038,7 +1038,9 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
         // three or so mask-free tiles, whose look-ahead rows have to be clamped) goes through the C++ form below.
         bool tripped = false;
         if constexpr (!SOFTCAP && !(FA_ABLATE & 32)) {
-            // (the descriptors address bytes with 32 bits: longer sequences stay on the C++ form)
+            // (the descriptors address bytes with 32 bits.  Longer sequences -- 1 GiB or more of K or V per (batch, kv head) --
+            //  run every half-step through generic_half: correct, about half the speed; the C++ form of the fast loop below is
+            //  only compiled for soft-cap kernels)
             const bool addr32 = (int64_t)sk * k_rs64 < (1ll << 30) && (int64_t)sk * v_rs64 < (1ll << 30);
             auto run_block = [&](auto masked_c, int count, bool restore_la) {
                 constexpr bool MASKED = decltype(masked_c)::value;

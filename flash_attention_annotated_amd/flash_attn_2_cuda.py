@@ -33,11 +33,12 @@ _window_rule = threading.local()
 
 @contextlib.contextmanager
 def fa3_window_rule():
+    prev = getattr(_window_rule, "fa3", False)
     _window_rule.fa3 = True
     try:
         yield
     finally:
-        _window_rule.fa3 = False
+        _window_rule.fa3 = prev   # (nested use keeps the outer rule)
 
 
 def _check(cond, msg):

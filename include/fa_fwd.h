@@ -123,9 +123,12 @@ typedef struct fa_fwd_params {
     int32_t kernel_variant;
     int32_t total_k;      /* varlen: rows of k/v (only needed for fp8 inputs: size of the expansion workspace) */
 
-    /* fp8 only: caller-provided scratch (the callee never allocates), 256-byte aligned, fa_fwd_workspace_size() bytes.
-     * The fp8 path expands q/k/v to bf16 (exact: every e4m3 value is a bf16 value) and runs the 16-bit mainloop with
-     * the descales folded into the softmax scale and the final normalisation. */
+    /* caller-provided scratch (the callee never allocates), 256-byte aligned, fa_fwd_workspace_size() bytes.
+     * fp8: head dim 128 (dense / varlen / causal / right window) runs natively -- e4m3 operands straight into the block-scaled
+     * MFMA, no workspace (fa_fwd_workspace_size() returns 0).  The other fp8 shapes (other head dims, softcap, left windows,
+     * K or V of 2 GiB or more per batch entry) expand q/k/v to bf16 here (exact: every e4m3 value is a bf16 value) and run the
+     * 16-bit mainloop; either way the descales are folded into the softmax scale and the final normalisation.
+     * 16-bit dense problems that split the key range (num_splits) keep their fp32 partial O / LSE here. */
     void *workspace;
     uint64_t workspace_bytes;
 

@@ -19,6 +19,10 @@ def ensure_library_is_built():
     the session loudly (content hash recorded by build(); the product itself never builds on demand either)."""
     import torch
     from flash_attention_annotated_amd import _lib
+    if os.environ.get("FA_FWD_LIB"):
+        # the developer override (ablation / instrumented builds) would silently swap the library under test: the staleness
+        # check below only covers the in-tree path
+        pytest.exit("FA_FWD_LIB is set: the test suite only runs against the in-tree libfa_fwd_gfx950.so", returncode=3)
     if torch.cuda.is_available():
         if _lib.is_stale():
             pytest.exit("libfa_fwd_gfx950.so is missing or stale on this GPU box: run `python -c 'import __graft_entry__ as g; "

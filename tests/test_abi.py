@@ -154,3 +154,34 @@ def test_kvcache_append_validate(built_lib):
     assert built_lib.fa_kvcache_append(ctypes.byref(p), None) == -1
     p.abi_version = 1
     assert built_lib.fa_kvcache_append(ctypes.byref(p), None) == -9
+
+
+def test_fp8_native_switch_is_pinned_by_workspace_size(built_lib):
+    """fp8 at head dim 128 runs natively (no workspace) only while one (batch, kv head)'s K and V stay below 2 GiB: the native
+    kernel addresses them through 32-bit raw buffer descriptors (fa_fwd_kernel_fp8.h), longer ones take the expansion path
+    (ADVICE round 2).  fa_fwd_workspace_size() returns 0 exactly for the native shapes."""
+    def fp8(seqlen_k, h_k=32, d=128):
+        p = _lib.new_params()
+        for f in ("q", "k", "v", "o", "softmax_lse"):
+            setattr(p, f, 0x10000)
+        p.b, p.seqlen_q, p.seqlen_k, p.h, p.h_k, p.d = 1, 256, seqlen_k, h_k, h_k, d
+        p.dtype = _lib.FA_DTYPE_FP8_E4M3
+        for t in ("q", "k", "v", "o"):
+            setattr(p, f"{t}_row_stride", h_k * d)
+            setattr(p, f"{t}_head_stride", d)
+        p.q_batch_stride = p.o_batch_stride = 256 * h_k * d
+        p.k_batch_stride = p.v_batch_stride = seqlen_k * h_k * d
+        p.softmax_scale = 0.088
+        p.window_size_left = p.window_size_right = -1
+        return p
+    size = lambda p: built_lib.fa_fwd_workspace_size(ctypes.byref(p))
+    assert size(fp8(8192)) == 0                          # BASELINE config 5's shape: native
+    assert size(fp8(8192, d=64)) > 0                     # other head dims: expansion workspace
+    assert size(fp8((1 << 31) // (32 * 128) - 1)) == 0   # last row still below 2 GiB
+    big = fp8((1 << 31) // (32 * 128))                   # seqlen_k * k_row_stride == 2^31 bytes
+    assert size(big) > 0
+    big.v_row_stride = 16                                # only K too long: still the expansion path
+    assert size(big) > 0
+    p = fp8(8192)
+    p.k_row_stride = 1 << 31                             # a row stride that does not fit an int
+    assert size(p) > 0

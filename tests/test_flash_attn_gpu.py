@@ -347,6 +347,53 @@ def test_rescale_branch_forced():
 
 
 @pytest.mark.parametrize("d", [128, 64])
+def test_phantom_trip_forced(d):
+    """Forces guard A / guard B of the generated loop to trip ON the phantom half-step: the block that runs a
+    wave's last unmasked tile also forms the scores of the half-step BEHIND it, and behind the end of a split-KV range those
+    are real keys.  A dominant key in the first 32 keys behind each split boundary makes the phantom's row sums (q-block A:
+    rows r < 32 of a wave) or its look-ahead max (q-block B) overflow the stale max -- deterministically, not 2 seeds in 24.
+    The same keys are ordinary keys of the next split, whose prologue must handle them; the merged result is compared
+    with the oracle.  sq 512 = 2 m-blocks x 4 waves, sk 2048 in 4 splits of 8 tiles: boundaries at keys 512 / 1024 / 1536."""
+    fa = _api()
+    torch.manual_seed(31)
+    sq, sk = 512, 2048
+    q = torch.randn(1, sq, 4, d, dtype=torch.bfloat16)
+    k = torch.randn(1, sk, 2, d, dtype=torch.bfloat16)
+    v = torch.randn(1, sk, 2, d, dtype=torch.bfloat16)
+    # (query row, key): rows 10 / 200 / 458 sit in a q-block A (row % 64 < 32), rows 300 / 120 in a q-block B
+    spikes = [(10, 512 + 5), (300, 1024 + 20), (200, 1536 + 31), (458, 512 + 17), (120, 1536 + 0)]
+    for i, (row, key) in enumerate(spikes):
+        k[0, key, i % 2] = q[0, row, 2 * (i % 2)] * 3.0   # head 0 / 2 of GQA group i % 2
+    out_ref, out_pt, lse_ref = _dense_ref(q, k, v)
+    for splits in (4, 1):
+        out, lse = fa.flash_attn_with_kvcache(q.to(DEV), k.to(DEV), v.to(DEV), num_splits=splits, return_softmax_lse=True)
+        _check(out, out_ref, out_pt, f"phantom trip, num_splits={splits}")
+        _check_lse(lse, lse_ref, tol=5e-3)
+
+
+@pytest.mark.parametrize("d", [128, 64])
+def test_block_boundary_trip_forced_causal(d):
+    """The causal twin: a dominant key in the first (diagonal) tile behind a wave's last unmasked tile trips the guards in the
+    LAST half-step of the unmasked generated block -- the exit where the generic half-step must redo P_A from the kept
+    scores and hand over to the MASKED block -- for rows of q-block A and of q-block B, in every wave of two m-blocks."""
+    fa = _api()
+    torch.manual_seed(32)
+    s = 2304                               # (> 2048: head dim 64 keeps the 256-row kernel under a causal mask)
+    q = torch.randn(1, s, 2, d, dtype=torch.bfloat16)
+    k = torch.randn(1, s, 2, d, dtype=torch.bfloat16)
+    v = torch.randn(1, s, 2, d, dtype=torch.bfloat16)
+    for mb in (2, 8):                      # m-blocks whose waves have >= 2 unmasked tiles in front of the diagonal
+        for w in range(4):
+            wrow = 256 * mb + 64 * w
+            row = wrow + (10 if w % 2 == 0 else 45)          # q-block A / q-block B
+            k[0, wrow + 2 + w, w % 2] = q[0, row, w % 2] * 3.0   # visible to `row` (key <= row), first half-step of the diagonal tile
+    out, lse, _ = fa.flash_attn_func(q.to(DEV), k.to(DEV), v.to(DEV), causal=True, return_attn_probs=True)
+    out_ref, out_pt, lse_ref = _dense_ref(q, k, v, causal=True)
+    _check(out, out_ref, out_pt, "forced trip at the unmasked/masked block boundary")
+    _check_lse(lse, lse_ref, tol=5e-3)
+
+
+@pytest.mark.parametrize("d", [128, 64])
 @pytest.mark.parametrize("variant", [0, 1, 2, 3])
 def test_kernel_variants_agree(variant, d):
     """Every tile shape the dispatcher can pick gives the same answer as the oracle (0 = the library's policy, which

@@ -133,3 +133,57 @@ def test_c5_fp8_full_size():
         kw = dict(q_descale=qd[bi:bi + 1], k_descale=kd[bi:bi + 1], v_descale=vd[bi:bi + 1])
         _check_rows(out[bi:bi + 1, rows], lse[bi:bi + 1, :, rows], q16[bi:bi + 1, rows], k16[bi:bi + 1], v16[bi:bi + 1], None,
                     f"C5 batch {bi}", fp8_kw=kw, lse_tol=5e-3)
+
+
+def _grad_bound(ref, pt):
+    """tests/test_flash_attn.py:1129-1132: |dX - dX_ref|max <= 3 |dX_pt - dX_ref|max (+ the FA3 atol, hopper/test_flash_attn.py:262-286)."""
+    ref = ref.float()
+    return 3 * (pt.float() - ref).abs().max().item() + 2 * (ref + 0.3 - 0.3 - ref).abs().max().item() + 1e-5
+
+
+@pytest.mark.parametrize("name,s,causal", [("C2", 8192, False), ("C3", 16384, True)])
+def test_backward_full_size(name, s, causal):
+    """Backward at the BASELINE sequence lengths (b1 of C2 / C3: h16 d128) against the oracle's autograd -- not properties:
+      * dQ for a >= 128-row sample with at least one row in every 256-row m-block, ALL heads (dQ_i only needs row i of q and
+        dout, so the oracle is differentiated on the row subset with the mask as an additive bias);
+      * dK and dV in FULL for 2 heads (every query row contributes: the full attention matrix of those heads).
+    This is where the generated dQ loop's cross-tile pipeline over three LDS slots and the dK/dV run-per-head logic execute
+    > 100 tiles per workgroup.  Bound: the reference's inequality with factor 3."""
+    fa = _api()
+    torch.manual_seed(0)
+    h, d = 16, 128
+    q = torch.randn(1, s, h, d, dtype=torch.bfloat16)
+    k = torch.randn(1, s, h, d, dtype=torch.bfloat16)
+    v = torch.randn(1, s, h, d, dtype=torch.bfloat16)
+    g = torch.randn(1, s, h, d, dtype=torch.bfloat16)
+    qd, kd, vd = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
+    out = fa.flash_attn_func(qd, kd, vd, causal=causal)
+    dq, dk, dv = (t.cpu() for t in torch.autograd.grad(out, (qd, kd, vd), g.to(DEV)))
+    del out, qd, kd, vd
+    assert all(torch.isfinite(t.float()).all() for t in (dq, dk, dv))
+
+    # dQ on the row sample, all heads
+    rows = sample_rows(s, n=128, block=256, seed=1)
+    idx = torch.tensor(rows)
+    bias = causal_bias(rows, s, s) if causal else None
+
+    def dq_rows(**kw):
+        ql = q[:, idx].clone().requires_grad_(True)
+        o = oracle.attention_ref(ql, k, v, attn_bias=bias, **kw)[0]
+        return torch.autograd.grad(o, ql, g[:, idx])[0]
+    ref, pt = dq_rows(), dq_rows(upcast=False, reorder_ops=True)
+    err = (dq[:, idx].float() - ref.float()).abs().max().item()
+    assert err <= _grad_bound(ref, pt), f"{name} dq rows: {err:.3e} > {_grad_bound(ref, pt):.3e}"
+
+    # dK / dV in full, one head at a time (16384^2 fp32 scores = 1 GiB per head)
+    for head in (3, 12):
+        sl = slice(head, head + 1)
+
+        def dkv(**kw):
+            kl, vl = (t[:, :, sl].clone().requires_grad_(True) for t in (k, v))
+            o = oracle.attention_ref(q[:, :, sl], kl, vl, causal=causal, **kw)[0]
+            return torch.autograd.grad(o, (kl, vl), g[:, :, sl])
+        (dk_ref, dv_ref), (dk_pt, dv_pt) = dkv(), dkv(upcast=False, reorder_ops=True)
+        for nm, got, r, p in (("dk", dk[:, :, sl], dk_ref, dk_pt), ("dv", dv[:, :, sl], dv_ref, dv_pt)):
+            err = (got.float() - r.float()).abs().max().item()
+            assert err <= _grad_bound(r, p), f"{name} {nm} head {head}: {err:.3e} > {_grad_bound(r, p):.3e}"

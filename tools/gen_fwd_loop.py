@@ -44,6 +44,17 @@ LD = 4                      # LDS-DMA pieces per wave and tile
 # developer-only timing ablations (results are WRONG when non-zero; `--ablate N --out path`, never committed):
 # 1 no LDS-DMA, 2 no guard checks, 4 no max look-ahead, 8 no softmax VALU, 16 no barrier
 ABLATE = 0
+# further developer-only ablation bits: 32 no phase-1 softmax VALU, 64 no phase-2 softmax VALU, 128 v_exp -> v_mov,
+# 256 no cvt, 512 no row-sum adds, 1024 no fma (the exp reads the raw score)
+# SCHED: placement of a score pair's 7 VALU around the slice's two MFMAs
+#   0  [MFMA A][fma fma exp exp][MFMA B][add add cvt]      (round 2)
+#   1  [MFMA A][fma fma exp][MFMA B][exp add add cvt]      (one transcendental per gap: MI355X_MICROARCH issue costs)
+#   2  [MFMA A][fma exp fma][MFMA B][exp add add cvt]
+# DSPOS: 0 = the slice's LDS fragment fetch in front of MFMA A, 1 = right behind it
+# LAPOS: 0 = look-ahead max at the end of the slice, 1 = behind the gap-1 VALU (in front of MFMA B)
+SCHED = 0
+DSPOS = 0
+LAPOS = 0
 
 # ---- register map (arch VGPRs) ----
 SA, SBX, SBY = 0, 16, 32
@@ -113,6 +124,29 @@ def cvt_f16(dst, t0, t1):
             f"v_cvt_f16_f32_sdwa {v(dst)}, {v(t1)} dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD"]
 
 
+def pair_parts(E, phase, s0, s1, mc, acc0, acc1, dst):
+    """The 7 VALU of one score pair as (gap 1, gap 2) instruction lists: t = exp2(s * c - mc); acc += t; dst = pack(t0, t1)."""
+    off = (ABLATE & 8) or (ABLATE & (32 if phase == 1 else 64))
+    if off:
+        return [], []
+    ex = "v_mov_b32" if ABLATE & 128 else "v_exp_f32"
+    fma0 = [f"v_fma_f32 {v(T0)}, {v(s0)}, %[csc], -{v(mc)}"]
+    fma1 = [f"v_fma_f32 {v(T1)}, {v(s1)}, %[csc], -{v(mc)}"]
+    exp0, exp1 = [f"{ex} {v(T0)}, {v(T0)}"], [f"{ex} {v(T1)}, {v(T1)}"]
+    if ABLATE & 1024:
+        fma0, fma1 = [], []
+        exp0, exp1 = [f"{ex} {v(T0)}, {v(s0)}"], [f"{ex} {v(T1)}, {v(s1)}"]
+    adds = [] if ABLATE & 512 else [f"v_add_f32 {v(acc0)}, {v(acc0)}, {v(T0)}", f"v_add_f32 {v(acc1)}, {v(acc1)}, {v(T1)}"]
+    cvt = [] if ABLATE & 256 else E.cvt(dst, T0, T1)
+    if SCHED == 0:
+        return fma0 + fma1 + exp0 + exp1, adds + cvt
+    if SCHED == 1:
+        return fma0 + fma1 + exp0, exp1 + adds + cvt
+    if SCHED == 2:
+        return fma0 + exp0 + fma1, exp1 + adds + cvt
+    raise ValueError(SCHED)
+
+
 def gen_half(E, slot, KB, uid):
     """One 32-key half-step of the tile in ring slot `slot`."""
     sb_cur, sb_nxt = (SBX, SBY) if KB == 0 else (SBY, SBX)
@@ -126,47 +160,39 @@ def gen_half(E, slot, KB, uid):
     mf = E.mfma
     E.e(f"; ---- slot {slot} half-step KB={KB}: phase 1")
     for ks in range(KSTEPS):
-        # LDS fragment fetch two slices ahead
-        if ks + 2 < KSTEPS:
-            E.ds_k(kf(ks + 2), ks + 2, kb_off, ("k", uid, ks + 2))
-        elif ks + 2 == KSTEPS:
-            E.ds_v(vf(0), 0, 0, vb_off, ("v", uid, 0))
-        else:
-            E.ds_v(vf(1), 0, 1, vb_off, ("v", uid, 1))
+        def fetch1():  # LDS fragment fetch two slices ahead
+            if ks + 2 < KSTEPS:
+                E.ds_k(kf(ks + 2), ks + 2, kb_off, ("k", uid, ks + 2))
+            elif ks + 2 == KSTEPS:
+                E.ds_v(vf(0), 0, 0, vb_off, ("v", uid, 0))
+            else:
+                E.ds_v(vf(1), 0, 1, vb_off, ("v", uid, 1))
+        if DSPOS == 0:
+            fetch1()
         if KB == 0 and ks == 0:
             E.e(f"s_add_u32 m0, %[lds_wave], {kdst}")
         E.wait_for(("k", uid, ks))
         c_a = "0" if ks == 0 else v(SA, 16)
         c_b = "0" if ks == 0 else v(sb_nxt, 16)
         E.e(f"{mf} {v(SA, 16)}, {v(kf(ks), 4)}, %[qa{ks}], {c_a}")
+        if DSPOS == 1:
+            fetch1()
         if KB == 0 and ks < LD and not (ABLATE & 1):
             # piece ks of K tile n+3: 1 KiB at M0 + 1024 ks (the instruction offset moves the LDS target AND the source: the
             # lane offsets carry -1024 ks); rows past the end of the sequence read as zeros (raw buffer, num_records)
             E.e(f"buffer_load_dwordx4 {v(KOFF + ks)}, %[kdesc], %[ktile] offen offset:{1024 * ks} lds")
         prs = pairs_of(ks, KSTEPS)
         pr = prs[0]
-        s0, s1 = sb_cur + 2 * pr, sb_cur + 2 * pr + 1
-        if not (ABLATE & 8):
-            E.e(f"v_fma_f32 {v(T0)}, {v(s0)}, %[csc], -{v(MCB)}")
-            E.e(f"v_fma_f32 {v(T1)}, {v(s1)}, %[csc], -{v(MCB)}")
-            E.e(f"v_exp_f32 {v(T0)}, {v(T0)}")
-            E.e(f"v_exp_f32 {v(T1)}, {v(T1)}")
+        g1, g2 = pair_parts(E, 1, sb_cur + 2 * pr, sb_cur + 2 * pr + 1, MCB, LB0, LB1, PB + pr)
+        for ins in g1:
+            E.e(ins)
         E.e(f"{mf} {v(sb_nxt, 16)}, {v(kf(ks), 4)}, %[qb{ks}], {c_b}")
-        if not (ABLATE & 8):
-            E.e(f"v_add_f32 {v(LB0)}, {v(LB0)}, {v(T0)}")
-            E.e(f"v_add_f32 {v(LB1)}, {v(LB1)}, {v(T1)}")
-            for ins in E.cvt(PB + pr, T0, T1):
+        for ins in g2:
+            E.e(ins)
+        for pr in prs[1:]:  # (DEFF = 96: 8 pairs over 6 slices)
+            g1, g2 = pair_parts(E, 1, sb_cur + 2 * pr, sb_cur + 2 * pr + 1, MCB, LB0, LB1, PB + pr)
+            for ins in g1 + g2:
                 E.e(ins)
-            for pr in prs[1:]:  # (DEFF = 96: 8 pairs over 6 slices)
-                s0, s1 = sb_cur + 2 * pr, sb_cur + 2 * pr + 1
-                E.e(f"v_fma_f32 {v(T0)}, {v(s0)}, %[csc], -{v(MCB)}")
-                E.e(f"v_fma_f32 {v(T1)}, {v(s1)}, %[csc], -{v(MCB)}")
-                E.e(f"v_exp_f32 {v(T0)}, {v(T0)}")
-                E.e(f"v_exp_f32 {v(T1)}, {v(T1)}")
-                E.e(f"v_add_f32 {v(LB0)}, {v(LB0)}, {v(T0)}")
-                E.e(f"v_add_f32 {v(LB1)}, {v(LB1)}, {v(T1)}")
-                for ins in E.cvt(PB + pr, T0, T1):
-                    E.e(ins)
     if KB == 0:  # K source of the next tile's DMA
         E.e("s_add_u32 %[ktile], %[ktile], %[kstep]")
     E.e(f"; ---- slot {slot} half-step KB={KB}: phase 2")
@@ -182,18 +208,23 @@ def gen_half(E, slot, KB, uid):
             E.wait_all()
             if not (ABLATE & 16):
                 E.e("s_barrier")
-        if t + 2 < NSTEP:
-            E.ds_v(vf(t + 2), (t + 2) >> 1, (t + 2) & 1, vb_off, ("v", uid, t + 2))
-        else:
-            nks = t + 2 - NSTEP  # first two K fragments of the next half-step
-            if KB == 0:
-                E.ds_k(kf(nks), nks, kb_off + 32 * ROWB, ("k", uid + 1, nks))
+        def fetch2():
+            if t + 2 < NSTEP:
+                E.ds_v(vf(t + 2), (t + 2) >> 1, (t + 2) & 1, vb_off, ("v", uid, t + 2))
             else:
-                E.ds_k(kf(nks), nks, ((slot + 2) % 3) * TILE, ("k", uid + 1, nks))
+                nks = t + 2 - NSTEP  # first two K fragments of the next half-step
+                if KB == 0:
+                    E.ds_k(kf(nks), nks, kb_off + 32 * ROWB, ("k", uid + 1, nks))
+                else:
+                    E.ds_k(kf(nks), nks, ((slot + 2) % 3) * TILE, ("k", uid + 1, nks))
+        if DSPOS == 0:
+            fetch2()
         if KB == 0 and t == 0:
             E.e(f"s_add_u32 m0, %[lds_wave], {vdst}")
         E.wait_for(("v", uid, t))
         E.e(f"{mf} %[oa{db}], {v(vf(t), 4)}, {v(pa_cur + 4 * st, 4)}, %[oa{db}]")
+        if DSPOS == 1:
+            fetch2()
         if KB == 0 and t < LD and not (ABLATE & 1):
             E.e(f"buffer_load_dwordx4 {v(VOFF + t)}, %[vdesc], %[vtile] offen offset:{1024 * t} lds")
         if MASKED and t == 0:
@@ -210,52 +241,54 @@ def gen_half(E, slot, KB, uid):
                 E.e(f"v_cndmask_b32 {v(sb_nxt + i)}, {v(sb_nxt + i)}, {v(NINF)}, vcc")
         prs = pairs_of(t, NSTEP)
         pr = prs[0]
-        s0, s1 = SA + 2 * pr, SA + 2 * pr + 1
         last = (t == NSTEP - 1) and not (ABLATE & 2)
-        if not (ABLATE & 8):
-            E.e(f"v_fma_f32 {v(T0)}, {v(s0)}, %[csc], -{v(MCA)}")
-            E.e(f"v_fma_f32 {v(T1)}, {v(s1)}, %[csc], -{v(MCA)}")
-            E.e(f"v_exp_f32 {v(T0)}, {v(T0)}")
-            E.e(f"v_exp_f32 {v(T1)}, {v(T1)}")
-        if last:
-            # guard B (look-ahead): some score of S_B(j+1) exceeds m_b + THR / c in ANY lane (each lane half holds its own
-            # 16 keys of the row: no cross-half max needed for a wave-wide "any")
-            E.e(f"v_max_f32 {v(NXA)}, {v(NXA)}, {v(NXB)}")
-            E.e(f"v_cmp_nge_f32 vcc, {v(MBT)}, {v(NXA)}")      # !(m_b + THR / c >= max)
-        E.e(f"{mf} %[ob{db}], {v(vf(t), 4)}, {v(PB + 4 * st, 4)}, %[ob{db}]")
-        if not (ABLATE & 8):
-            E.e(f"v_add_f32 {v(PSA0)}, {v(PSA0)}, {v(T0)}")
-            E.e(f"v_add_f32 {v(PSA1)}, {v(PSA1)}, {v(T1)}")
-            if last:
-                E.e("s_mov_b64 %[bflag], vcc")
-                if len(prs) == 1:
-                    E.e(f"v_add_f32 {v(TMP)}, {v(PSA0)}, {v(PSA1)}")
-            for ins in E.cvt(pa_nxt + pr, T0, T1):
-                E.e(ins)
-            for pr in prs[1:]:
-                s0, s1 = SA + 2 * pr, SA + 2 * pr + 1
-                E.e(f"v_fma_f32 {v(T0)}, {v(s0)}, %[csc], -{v(MCA)}")
-                E.e(f"v_fma_f32 {v(T1)}, {v(s1)}, %[csc], -{v(MCA)}")
-                E.e(f"v_exp_f32 {v(T0)}, {v(T0)}")
-                E.e(f"v_exp_f32 {v(T1)}, {v(T1)}")
-                E.e(f"v_add_f32 {v(PSA0)}, {v(PSA0)}, {v(T0)}")
-                E.e(f"v_add_f32 {v(PSA1)}, {v(PSA1)}, {v(T1)}")
-                for ins in E.cvt(pa_nxt + pr, T0, T1):
-                    E.e(ins)
-            if last and len(prs) > 1:
-                E.e(f"v_add_f32 {v(TMP)}, {v(PSA0)}, {v(PSA1)}")
+        valu = not ((ABLATE & 8) or (ABLATE & 64))
+        g1, g2 = pair_parts(E, 2, SA + 2 * pr, SA + 2 * pr + 1, MCA, PSA0, PSA1, pa_nxt + pr)
+        nadd = 0 if ABLATE & 512 else 2      # gap 2 = [exp?] adds | rest: the guard's scalar copies sit behind the adds
+        nexp2 = len(g2) - nadd - (0 if ABLATE & 256 else len(E.cvt(0, 0, 0)))
+        for ins in g1:
+            E.e(ins)
         # look-ahead max of S_B(j+1) (complete since the end of phase 1), two v_max3 per slice over four slices that end
         # two slices before the guard
         nmax = min(4, NSTEP - 2)          # slices that carry the look-ahead max (16 registers: 4 or 8 per slice)
         m0_ = NSTEP - 2 - nmax
         if MASKED:
             m0_ = max(m0_, 1)  # (registers 4k..4k+3 are masked in slice k: read them from slice k+1 on)
-        if m0_ <= t < m0_ + nmax and not (ABLATE & 4):
-            per = 16 // nmax
-            for i in range((t - m0_) * per, (t - m0_ + 1) * per, 4):
-                first = (i == 0)
-                E.e(f"v_max3_f32 {v(NXA)}, {v(sb_nxt + i)}, {v(sb_nxt + i + 1)}, {v(MB) if first else v(NXA)}")
-                E.e(f"v_max3_f32 {v(NXB)}, {v(sb_nxt + i + 2)}, {v(sb_nxt + i + 3)}, {v(MB) if first else v(NXB)}")
+        def lookahead():
+            if m0_ <= t < m0_ + nmax and not (ABLATE & 4):
+                per = 16 // nmax
+                for i in range((t - m0_) * per, (t - m0_ + 1) * per, 4):
+                    first = (i == 0)
+                    E.e(f"v_max3_f32 {v(NXA)}, {v(sb_nxt + i)}, {v(sb_nxt + i + 1)}, {v(MB) if first else v(NXA)}")
+                    E.e(f"v_max3_f32 {v(NXB)}, {v(sb_nxt + i + 2)}, {v(sb_nxt + i + 3)}, {v(MB) if first else v(NXB)}")
+        if LAPOS == 1:
+            lookahead()
+        if last:
+            # guard B (look-ahead): some score of S_B(j+1) exceeds m_b + THR / c in ANY lane (each lane half holds its own
+            # 16 keys of the row: no cross-half max needed for a wave-wide "any")
+            E.e(f"v_max_f32 {v(NXA)}, {v(NXA)}, {v(NXB)}")
+            E.e(f"v_cmp_nge_f32 vcc, {v(MBT)}, {v(NXA)}")      # !(m_b + THR / c >= max)
+        E.e(f"{mf} %[ob{db}], {v(vf(t), 4)}, {v(PB + 4 * st, 4)}, %[ob{db}]")
+        if valu:
+            for ins in g2[:nexp2 + nadd]:
+                E.e(ins)
+            if last:
+                E.e("s_mov_b64 %[bflag], vcc")
+                if len(prs) == 1:
+                    E.e(f"v_add_f32 {v(TMP)}, {v(PSA0)}, {v(PSA1)}")
+            for ins in g2[nexp2 + nadd:]:
+                E.e(ins)
+            for pr in prs[1:]:
+                g1, g2 = pair_parts(E, 2, SA + 2 * pr, SA + 2 * pr + 1, MCA, PSA0, PSA1, pa_nxt + pr)
+                for ins in g1 + g2:
+                    E.e(ins)
+            if last and len(prs) > 1:
+                E.e(f"v_add_f32 {v(TMP)}, {v(PSA0)}, {v(PSA1)}")
+        elif last:   # (timing ablation: keep the guard's plumbing)
+            E.e("s_mov_b64 %[bflag], vcc")
+            E.e(f"v_add_f32 {v(TMP)}, {v(PSA0)}, {v(PSA1)}")
+        if LAPOS == 0:
+            lookahead()
     if KB == 0:
         E.e("s_add_u32 %[vtile], %[vtile], %[vstep]")
     if MASKED:  # the next half-step's scores start 32 keys further on
@@ -400,11 +433,15 @@ def render(lines):
 
 
 def main():
-    global ABLATE
+    global ABLATE, SCHED, DSPOS, LAPOS
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     path = os.path.join(root, "flash_attention_annotated_amd", "csrc", "fa_fwd_loop_gen.h")
     if "--ablate" in sys.argv:
         ABLATE = int(sys.argv[sys.argv.index("--ablate") + 1])
+    for name in ("sched", "dspos", "lapos"):   # developer-only schedule variants (with --out)
+        if f"--{name}" in sys.argv:
+            globals()[name.upper()] = int(sys.argv[sys.argv.index(f"--{name}") + 1])
+    if "--out" in sys.argv:
         path = sys.argv[sys.argv.index("--out") + 1]
     global D, ROWB, TILE, LD, DEFF, KSTEPS, NSTEP, MASKED
     text = HEADER
