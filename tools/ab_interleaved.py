@@ -50,6 +50,16 @@ for sh in shapes:
         for n in libs:
             _lib._lib = handles[n]
             res[n].append(t(lambda: fa.flash_attn_func(q, k, v, causal=causal)))
+    outs = {}
+    for n in libs:   # the builds must agree (schedule variants are bit-identical by construction)
+        _lib._lib = handles[n]
+        o, lse, _ = fa.flash_attn_func(q, k, v, causal=causal, return_attn_probs=True)
+        outs[n] = (o.float(), lse.float())
+    for n in libs[1:]:
+        do = (outs[n][0] - outs[libs[0]][0]).abs().max().item()
+        dl = (outs[n][1] - outs[libs[0]][1]).abs().max().item()
+        if do != 0 or dl != 0:
+            print(f"   !! {os.path.basename(n)} differs from {os.path.basename(libs[0])}: out {do:.3e} lse {dl:.3e}", flush=True)
     for n in libs:
         ms = sorted(res[n])
         print(f"{sh:7s} {os.path.basename(n):28s} median {fl / ms[len(ms) // 2] / 1e9:7.1f}  best {fl / ms[0] / 1e9:7.1f} TFLOP/s   ({ms[len(ms) // 2]:.4f} ms)", flush=True)

@@ -46,15 +46,15 @@ LD = 4                      # LDS-DMA pieces per wave and tile
 ABLATE = 0
 # further developer-only ablation bits: 32 no phase-1 softmax VALU, 64 no phase-2 softmax VALU, 128 v_exp -> v_mov,
 # 256 no cvt, 512 no row-sum adds, 1024 no fma (the exp reads the raw score)
-# SCHED: placement of a score pair's 7 VALU around the slice's two MFMAs
-#   0  [MFMA A][fma fma exp exp][MFMA B][add add cvt]      (round 2)
-#   1  [MFMA A][fma fma exp][MFMA B][exp add add cvt]      (one transcendental per gap: MI355X_MICROARCH issue costs)
-#   2  [MFMA A][fma exp fma][MFMA B][exp add add cvt]
-# DSPOS: 0 = the slice's LDS fragment fetch in front of MFMA A, 1 = right behind it
-# LAPOS: 0 = look-ahead max at the end of the slice, 1 = behind the gap-1 VALU (in front of MFMA B)
-SCHED = 0
-DSPOS = 0
-LAPOS = 0
+# SLICE: the order of one slice's instructions (both phases), tokens:
+#   w  wait for this slice's LDS fragment   wn  ... for the NEXT slice's   A / B  the two MFMAs (q-blocks A and B)
+#   ds fetch of the fragment FD slices ahead   f0 f1 e0 e1 a0 a1 c  the score pair's fma / exp / row-sum adds / pack   la look-ahead max
+# Round 2 was "ds w A f0 f1 e0 e1 B a0 a1 c" (2638 cycles per tile at C2).  Round 3 (profiles/r3_sched_sweep*.txt): LDS and wait
+# instructions issue for free right behind an MFMA (the MFMA holds the VALU port for 8 cycles, not the LDS / scalar ports),
+# anywhere else they push the gap over its 24 cycles of VALU; and one transcendental per gap: 2420 - 2450 cycles, C2 +3.0 - 3.5 %.
+SLICE = "A ds f0 f1 e0 B wn e1 a0 a1 c"
+FD = 2          # LDS fragments are fetched FD slices ahead of their MFMAs (fragment rings of FD + 1 tuples)
+FIRSTPAIR = 1   # 1: the first pair of a phase-2 row sum exponentiates straight into the sum registers (no zeroing, no adds)
 
 # ---- register map (arch VGPRs) ----
 SA, SBX, SBY = 0, 16, 32
@@ -124,27 +124,32 @@ def cvt_f16(dst, t0, t1):
             f"v_cvt_f16_f32_sdwa {v(dst)}, {v(t1)} dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD"]
 
 
-def pair_parts(E, phase, s0, s1, mc, acc0, acc1, dst):
-    """The 7 VALU of one score pair as (gap 1, gap 2) instruction lists: t = exp2(s * c - mc); acc += t; dst = pack(t0, t1)."""
+def pair_ops(E, phase, s0, s1, mc, acc0, acc1, dst, direct=False, tmp=None):
+    """The VALU of one score pair by token: t = exp2(s * c - mc); acc += t; dst = pack(t0, t1).
+    direct: the exponentials land in the accumulators themselves (first pair of a fresh sum: no adds)."""
     off = (ABLATE & 8) or (ABLATE & (32 if phase == 1 else 64))
     if off:
-        return [], []
+        return {k: [] for k in ("f0", "f1", "e0", "e1", "a0", "a1", "c")}
+    TT0, TT1 = tmp if tmp else (T0, T1)
+    t0, t1 = (acc0, acc1) if direct else (TT0, TT1)
     ex = "v_mov_b32" if ABLATE & 128 else "v_exp_f32"
-    fma0 = [f"v_fma_f32 {v(T0)}, {v(s0)}, %[csc], -{v(mc)}"]
-    fma1 = [f"v_fma_f32 {v(T1)}, {v(s1)}, %[csc], -{v(mc)}"]
-    exp0, exp1 = [f"{ex} {v(T0)}, {v(T0)}"], [f"{ex} {v(T1)}, {v(T1)}"]
+    ops = {"f0": [f"v_fma_f32 {v(t0)}, {v(s0)}, %[csc], -{v(mc)}"], "f1": [f"v_fma_f32 {v(t1)}, {v(s1)}, %[csc], -{v(mc)}"],
+           "e0": [f"{ex} {v(t0)}, {v(t0)}"], "e1": [f"{ex} {v(t1)}, {v(t1)}"],
+           "a0": [f"v_add_f32 {v(acc0)}, {v(acc0)}, {v(TT0)}"], "a1": [f"v_add_f32 {v(acc1)}, {v(acc1)}, {v(TT1)}"],
+           "c": E.cvt(dst, t0, t1)}
     if ABLATE & 1024:
-        fma0, fma1 = [], []
-        exp0, exp1 = [f"{ex} {v(T0)}, {v(s0)}"], [f"{ex} {v(T1)}, {v(s1)}"]
-    adds = [] if ABLATE & 512 else [f"v_add_f32 {v(acc0)}, {v(acc0)}, {v(T0)}", f"v_add_f32 {v(acc1)}, {v(acc1)}, {v(T1)}"]
-    cvt = [] if ABLATE & 256 else E.cvt(dst, T0, T1)
-    if SCHED == 0:
-        return fma0 + fma1 + exp0 + exp1, adds + cvt
-    if SCHED == 1:
-        return fma0 + fma1 + exp0, exp1 + adds + cvt
-    if SCHED == 2:
-        return fma0 + exp0 + fma1, exp1 + adds + cvt
-    raise ValueError(SCHED)
+        ops["f0"], ops["f1"] = [], []
+        ops["e0"], ops["e1"] = [f"{ex} {v(t0)}, {v(s0)}"], [f"{ex} {v(t1)}, {v(s1)}"]
+    if (ABLATE & 512) or direct:
+        ops["a0"], ops["a1"] = [], []
+    if direct:
+        ops["a0"] = ["s_nop 0"]   # (keeps one instruction between the second v_exp and the pack that reads it)
+    if ABLATE & 256:
+        ops["c"] = []
+    return ops
+
+
+PAIR_TOKENS = ("f0", "f1", "e0", "e1", "a0", "a1", "c")
 
 
 def gen_half(E, slot, KB, uid):
@@ -155,99 +160,89 @@ def gen_half(E, slot, KB, uid):
     vb_off = slot * TILE + KB * 32 * ROWB                  # V rows of half-step j (VA carries the V region base)
     kdst = slot * TILE                                     # LDS-DMA targets of this tile: K tile n+3 -> K ring slot `slot`,
     vdst = (3 + (slot + 2) % 3) * TILE                     #                               V tile n+2 -> V ring slot (slot+2)%3
-    kf = lambda i: KF + 4 * (i % 3)
-    vf = lambda i: VF + 4 * (i % 3)
+    RING = FD + 1
+    kf = lambda i: KF + 4 * (i % RING)
+    vf = lambda i: VF + 4 * (i % RING)
     mf = E.mfma
+    tokens = SLICE.split()
     E.e(f"; ---- slot {slot} half-step KB={KB}: phase 1")
+    # fragment stream of a half-step: K fragments 0 .. KSTEPS-1 (phase 1), V^T fragments 0 .. NSTEP-1 (phase 2), then the next
+    # half-step's K fragments; slice i of the stream fetches element i + FD
+    def fetch(i):
+        if i < KSTEPS:
+            E.ds_k(kf(i), i, kb_off, ("k", uid, i))
+        elif i < KSTEPS + NSTEP:
+            t = i - KSTEPS
+            E.ds_v(vf(t), t >> 1, t & 1, vb_off, ("v", uid, t))
+        else:
+            nks = i - KSTEPS - NSTEP  # first FD K fragments of the next half-step
+            off = kb_off + 32 * ROWB if KB == 0 else ((slot + 2) % 3) * TILE
+            E.ds_k(kf(nks), nks, off, ("k", uid + 1, nks))
+    def tag_of(i):
+        if i < KSTEPS:
+            return ("k", uid, i)
+        if i < KSTEPS + NSTEP:
+            return ("v", uid, i - KSTEPS)
+        return ("k", uid + 1, i - KSTEPS - NSTEP)
     for ks in range(KSTEPS):
-        def fetch1():  # LDS fragment fetch two slices ahead
-            if ks + 2 < KSTEPS:
-                E.ds_k(kf(ks + 2), ks + 2, kb_off, ("k", uid, ks + 2))
-            elif ks + 2 == KSTEPS:
-                E.ds_v(vf(0), 0, 0, vb_off, ("v", uid, 0))
-            else:
-                E.ds_v(vf(1), 0, 1, vb_off, ("v", uid, 1))
-        if DSPOS == 0:
-            fetch1()
-        if KB == 0 and ks == 0:
-            E.e(f"s_add_u32 m0, %[lds_wave], {kdst}")
-        E.wait_for(("k", uid, ks))
         c_a = "0" if ks == 0 else v(SA, 16)
         c_b = "0" if ks == 0 else v(sb_nxt, 16)
-        E.e(f"{mf} {v(SA, 16)}, {v(kf(ks), 4)}, %[qa{ks}], {c_a}")
-        if DSPOS == 1:
-            fetch1()
-        if KB == 0 and ks < LD and not (ABLATE & 1):
-            # piece ks of K tile n+3: 1 KiB at M0 + 1024 ks (the instruction offset moves the LDS target AND the source: the
-            # lane offsets carry -1024 ks); rows past the end of the sequence read as zeros (raw buffer, num_records)
-            E.e(f"buffer_load_dwordx4 {v(KOFF + ks)}, %[kdesc], %[ktile] offen offset:{1024 * ks} lds")
         prs = pairs_of(ks, KSTEPS)
-        pr = prs[0]
-        g1, g2 = pair_parts(E, 1, sb_cur + 2 * pr, sb_cur + 2 * pr + 1, MCB, LB0, LB1, PB + pr)
-        for ins in g1:
-            E.e(ins)
-        E.e(f"{mf} {v(sb_nxt, 16)}, {v(kf(ks), 4)}, %[qb{ks}], {c_b}")
-        for ins in g2:
-            E.e(ins)
+        ops = pair_ops(E, 1, sb_cur + 2 * prs[0], sb_cur + 2 * prs[0] + 1, MCB, LB0, LB1, PB + prs[0])
+        for tok in tokens:
+            if tok == "ds":
+                fetch(ks + FD)
+            elif tok == "w":
+                if KB == 0 and ks == 0:
+                    E.e(f"s_add_u32 m0, %[lds_wave], {kdst}")
+                E.wait_for(tag_of(ks))
+            elif tok == "wn":
+                E.wait_for(tag_of(ks + 1))
+            elif tok == "A":
+                if "w" not in tokens:
+                    if KB == 0 and ks == 0:
+                        E.e(f"s_add_u32 m0, %[lds_wave], {kdst}")
+                    E.wait_for(tag_of(ks))   # (no-op when an earlier `wn` covered it)
+                E.e(f"{mf} {v(SA, 16)}, {v(kf(ks), 4)}, %[qa{ks}], {c_a}")
+                if KB == 0 and ks < LD and not (ABLATE & 1):
+                    # piece ks of K tile n+3: 1 KiB at M0 + 1024 ks (the instruction offset moves the LDS target AND the source:
+                    # the lane offsets carry -1024 ks); rows past the end of the sequence read as zeros (raw buffer, num_records)
+                    E.e(f"buffer_load_dwordx4 {v(KOFF + ks)}, %[kdesc], %[ktile] offen offset:{1024 * ks} lds")
+            elif tok == "B":
+                E.e(f"{mf} {v(sb_nxt, 16)}, {v(kf(ks), 4)}, %[qb{ks}], {c_b}")
+            elif tok in PAIR_TOKENS:
+                for ins in ops[tok]:
+                    E.e(ins)
+            elif tok == "la":
+                pass
+            else:
+                raise ValueError(tok)
         for pr in prs[1:]:  # (DEFF = 96: 8 pairs over 6 slices)
-            g1, g2 = pair_parts(E, 1, sb_cur + 2 * pr, sb_cur + 2 * pr + 1, MCB, LB0, LB1, PB + pr)
-            for ins in g1 + g2:
-                E.e(ins)
+            more = pair_ops(E, 1, sb_cur + 2 * pr, sb_cur + 2 * pr + 1, MCB, LB0, LB1, PB + pr)
+            for tok in PAIR_TOKENS:
+                for ins in more[tok]:
+                    E.e(ins)
     if KB == 0:  # K source of the next tile's DMA
         E.e("s_add_u32 %[ktile], %[ktile], %[kstep]")
     E.e(f"; ---- slot {slot} half-step KB={KB}: phase 2")
-    E.e(f"v_mov_b32 {v(PSA0)}, 0")
-    E.e(f"v_mov_b32 {v(PSA1)}, 0")
+    valu = not ((ABLATE & 8) or (ABLATE & 64))
+    direct = FIRSTPAIR and valu and not (ABLATE & 512)
+    if not direct:
+        E.e(f"v_mov_b32 {v(PSA0)}, 0")
+        E.e(f"v_mov_b32 {v(PSA1)}, 0")
     for t in range(NSTEP):
         db, st = t >> 1, t & 1
-        if KB == 1 and t == NSTEP - 2:
-            # tile barrier, two slices early: every K/V read of this tile has been issued; the DMA pieces issued one tile ago
+        if KB == 1 and t == NSTEP - FD:
+            # tile barrier, FD slices early: every K/V read of this tile has been issued; the DMA pieces issued one tile ago
             # (all but this tile's 2 LD youngest) have landed.  Behind it the next tile's first K fragments are fetched
-            # under the last two slices' MFMAs.
+            # under the last slices' MFMAs.
             E.e(f"s_waitcnt vmcnt({2 * LD}) lgkmcnt(0)")
             E.wait_all()
             if not (ABLATE & 16):
                 E.e("s_barrier")
-        def fetch2():
-            if t + 2 < NSTEP:
-                E.ds_v(vf(t + 2), (t + 2) >> 1, (t + 2) & 1, vb_off, ("v", uid, t + 2))
-            else:
-                nks = t + 2 - NSTEP  # first two K fragments of the next half-step
-                if KB == 0:
-                    E.ds_k(kf(nks), nks, kb_off + 32 * ROWB, ("k", uid + 1, nks))
-                else:
-                    E.ds_k(kf(nks), nks, ((slot + 2) % 3) * TILE, ("k", uid + 1, nks))
-        if DSPOS == 0:
-            fetch2()
-        if KB == 0 and t == 0:
-            E.e(f"s_add_u32 m0, %[lds_wave], {vdst}")
-        E.wait_for(("v", uid, t))
-        E.e(f"{mf} %[oa{db}], {v(vf(t), 4)}, {v(pa_cur + 4 * st, 4)}, %[oa{db}]")
-        if DSPOS == 1:
-            fetch2()
-        if KB == 0 and t < LD and not (ABLATE & 1):
-            E.e(f"buffer_load_dwordx4 {v(VOFF + t)}, %[vdesc], %[vtile] offen offset:{1024 * t} lds")
-        if MASKED and t == 0:
-            # mask of S_A(j+1) (complete since the last MFMA A of phase 1), before its first score is exponentiated: register i
-            # is key base + keyoff(i); masked iff keyoff(i) > RA = (last visible key of this lane's row A) - key base
-            for i in range(16):
-                E.e(f"v_cmp_gt_i32 vcc, {keyoff(i)}, {v(RA)}")
-                E.e(f"v_cndmask_b32 {v(SA + i)}, {v(SA + i)}, {v(NINF)}, vcc")
-        nmask = 4 if NSTEP >= 6 else 2   # slices that carry the mask of S_B(j+1): 4 (or 8) registers each
-        if MASKED and t < nmask:
-            # mask of S_B(j+1), ahead of the look-ahead max that reads each register at least one slice later
-            for i in range((16 // nmask) * t, (16 // nmask) * (t + 1)):
-                E.e(f"v_cmp_gt_i32 vcc, {keyoff(i)}, {v(RB)}")
-                E.e(f"v_cndmask_b32 {v(sb_nxt + i)}, {v(sb_nxt + i)}, {v(NINF)}, vcc")
         prs = pairs_of(t, NSTEP)
-        pr = prs[0]
         last = (t == NSTEP - 1) and not (ABLATE & 2)
-        valu = not ((ABLATE & 8) or (ABLATE & 64))
-        g1, g2 = pair_parts(E, 2, SA + 2 * pr, SA + 2 * pr + 1, MCA, PSA0, PSA1, pa_nxt + pr)
-        nadd = 0 if ABLATE & 512 else 2      # gap 2 = [exp?] adds | rest: the guard's scalar copies sit behind the adds
-        nexp2 = len(g2) - nadd - (0 if ABLATE & 256 else len(E.cvt(0, 0, 0)))
-        for ins in g1:
-            E.e(ins)
+        ops = pair_ops(E, 2, SA + 2 * prs[0], SA + 2 * prs[0] + 1, MCA, PSA0, PSA1, pa_nxt + prs[0], direct=direct and t == 0)
         # look-ahead max of S_B(j+1) (complete since the end of phase 1), two v_max3 per slice over four slices that end
         # two slices before the guard
         nmax = min(4, NSTEP - 2)          # slices that carry the look-ahead max (16 registers: 4 or 8 per slice)
@@ -261,33 +256,62 @@ def gen_half(E, slot, KB, uid):
                     first = (i == 0)
                     E.e(f"v_max3_f32 {v(NXA)}, {v(sb_nxt + i)}, {v(sb_nxt + i + 1)}, {v(MB) if first else v(NXA)}")
                     E.e(f"v_max3_f32 {v(NXB)}, {v(sb_nxt + i + 2)}, {v(sb_nxt + i + 3)}, {v(MB) if first else v(NXB)}")
-        if LAPOS == 1:
-            lookahead()
-        if last:
-            # guard B (look-ahead): some score of S_B(j+1) exceeds m_b + THR / c in ANY lane (each lane half holds its own
-            # 16 keys of the row: no cross-half max needed for a wave-wide "any")
-            E.e(f"v_max_f32 {v(NXA)}, {v(NXA)}, {v(NXB)}")
-            E.e(f"v_cmp_nge_f32 vcc, {v(MBT)}, {v(NXA)}")      # !(m_b + THR / c >= max)
-        E.e(f"{mf} %[ob{db}], {v(vf(t), 4)}, {v(PB + 4 * st, 4)}, %[ob{db}]")
-        if valu:
-            for ins in g2[:nexp2 + nadd]:
-                E.e(ins)
-            if last:
-                E.e("s_mov_b64 %[bflag], vcc")
-                if len(prs) == 1:
-                    E.e(f"v_add_f32 {v(TMP)}, {v(PSA0)}, {v(PSA1)}")
-            for ins in g2[nexp2 + nadd:]:
-                E.e(ins)
-            for pr in prs[1:]:
-                g1, g2 = pair_parts(E, 2, SA + 2 * pr, SA + 2 * pr + 1, MCA, PSA0, PSA1, pa_nxt + pr)
-                for ins in g1 + g2:
+        la_done = False
+        for tok in tokens:
+            if tok == "ds":
+                fetch(KSTEPS + t + FD)
+            elif tok == "w":
+                if KB == 0 and t == 0:
+                    E.e(f"s_add_u32 m0, %[lds_wave], {vdst}")
+                E.wait_for(tag_of(KSTEPS + t))
+            elif tok == "wn":
+                if not (KB == 1 and t == NSTEP - 1):   # (the next half-step's entry waits itself: other tile, other tags)
+                    E.wait_for(tag_of(KSTEPS + t + 1))
+            elif tok == "A":
+                if "w" not in tokens:
+                    if KB == 0 and t == 0:
+                        E.e(f"s_add_u32 m0, %[lds_wave], {vdst}")
+                    E.wait_for(tag_of(KSTEPS + t))
+                E.e(f"{mf} %[oa{db}], {v(vf(t), 4)}, {v(pa_cur + 4 * st, 4)}, %[oa{db}]")
+                if KB == 0 and t < LD and not (ABLATE & 1):
+                    E.e(f"buffer_load_dwordx4 {v(VOFF + t)}, %[vdesc], %[vtile] offen offset:{1024 * t} lds")
+                if MASKED and t == 0:
+                    # mask of S_A(j+1) (complete since the last MFMA A of phase 1), before its first score is exponentiated:
+                    # register i is key base + keyoff(i); masked iff keyoff(i) > RA = (last visible key of this lane's row A) - key base
+                    for i in range(16):
+                        E.e(f"v_cmp_gt_i32 vcc, {keyoff(i)}, {v(RA)}")
+                        E.e(f"v_cndmask_b32 {v(SA + i)}, {v(SA + i)}, {v(NINF)}, vcc")
+                nmask = 4 if NSTEP >= 6 else 2   # slices that carry the mask of S_B(j+1): 4 (or 8) registers each
+                if MASKED and t < nmask:
+                    # mask of S_B(j+1), ahead of the look-ahead max that reads each register at least one slice later
+                    for i in range((16 // nmask) * t, (16 // nmask) * (t + 1)):
+                        E.e(f"v_cmp_gt_i32 vcc, {keyoff(i)}, {v(RB)}")
+                        E.e(f"v_cndmask_b32 {v(sb_nxt + i)}, {v(sb_nxt + i)}, {v(NINF)}, vcc")
+            elif tok == "B":
+                if last:
+                    # guard B (look-ahead): some score of S_B(j+1) exceeds m_b + THR / c in ANY lane (each lane half holds its
+                    # own 16 keys of the row: no cross-half max needed for a wave-wide "any")
+                    E.e(f"v_max_f32 {v(NXA)}, {v(NXA)}, {v(NXB)}")
+                    E.e(f"v_cmp_nge_f32 vcc, {v(MBT)}, {v(NXA)}")      # !(m_b + THR / c >= max)
+                E.e(f"{mf} %[ob{db}], {v(vf(t), 4)}, {v(PB + 4 * st, 4)}, %[ob{db}]")
+                if last:
+                    E.e("s_mov_b64 %[bflag], vcc")
+            elif tok in PAIR_TOKENS:
+                for ins in ops[tok]:
                     E.e(ins)
-            if last and len(prs) > 1:
-                E.e(f"v_add_f32 {v(TMP)}, {v(PSA0)}, {v(PSA1)}")
-        elif last:   # (timing ablation: keep the guard's plumbing)
-            E.e("s_mov_b64 %[bflag], vcc")
+            elif tok == "la":
+                lookahead()
+                la_done = True
+            else:
+                raise ValueError(tok)
+        for pr in prs[1:]:
+            more = pair_ops(E, 2, SA + 2 * pr, SA + 2 * pr + 1, MCA, PSA0, PSA1, pa_nxt + pr)
+            for tok in PAIR_TOKENS:
+                for ins in more[tok]:
+                    E.e(ins)
+        if last:
             E.e(f"v_add_f32 {v(TMP)}, {v(PSA0)}, {v(PSA1)}")
-        if LAPOS == 0:
+        if not la_done:
             lookahead()
     if KB == 0:
         E.e("s_add_u32 %[vtile], %[vtile], %[vstep]")
@@ -331,13 +355,13 @@ def gen_block(mfma, cvt):
         if s:
             E.label(f".Lfa_in{s}_{u}")
         E.lds_q = []
-        E.ds_k(KF, 0, ((s + 1) % 3) * TILE, ("k", 1000 + 2 * s, 0))
-        E.ds_k(KF + 4, 1, ((s + 1) % 3) * TILE, ("k", 1000 + 2 * s, 1))
+        for i in range(FD):
+            E.ds_k(KF + 4 * i, i, ((s + 1) % 3) * TILE, ("k", 1000 + 2 * s, i))
         E.e(f"s_branch .Lfa_t{s}_{u}")
     uid = 1000
     for s in range(3):
         E.label(f".Lfa_t{s}_{u}")
-        E.lds_q = [("k", 1000 + 2 * s, 0), ("k", 1000 + 2 * s, 1)]
+        E.lds_q = [("k", 1000 + 2 * s, i) for i in range(FD)]
         gen_half(E, s, 0, 1000 + 2 * s)
         gen_half(E, s, 1, 1000 + 2 * s + 1)
         # (the K fragments fetched at the end of KB = 1 carry uid 1000 + 2 s + 2 = the next slot's KB = 0 tags; for slot 2 they
@@ -433,17 +457,21 @@ def render(lines):
 
 
 def main():
-    global ABLATE, SCHED, DSPOS, LAPOS
+    global ABLATE
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     path = os.path.join(root, "flash_attention_annotated_amd", "csrc", "fa_fwd_loop_gen.h")
     if "--ablate" in sys.argv:
         ABLATE = int(sys.argv[sys.argv.index("--ablate") + 1])
-    for name in ("sched", "dspos", "lapos"):   # developer-only schedule variants (with --out)
+    for name in ("fd", "firstpair"):   # developer-only schedule variants (with --out)
         if f"--{name}" in sys.argv:
             globals()[name.upper()] = int(sys.argv[sys.argv.index(f"--{name}") + 1])
+    if "--slice" in sys.argv:
+        globals()["SLICE"] = sys.argv[sys.argv.index("--slice") + 1].replace("_", " ")
     if "--out" in sys.argv:
         path = sys.argv[sys.argv.index("--out") + 1]
-    global D, ROWB, TILE, LD, DEFF, KSTEPS, NSTEP, MASKED
+    global D, ROWB, TILE, LD, DEFF, KSTEPS, NSTEP, MASKED, KF, VF
+    if FD == 3:
+        KF, VF = 156, 172   # 4 x 4 each
     text = HEADER
     # (head-dim tile, dims contracted, masked variant?)
     configs = [(128, 128, False), (128, 96, False), (128, 128, True), (128, 96, True), (64, 64, False), (64, 64, True)]
@@ -451,7 +479,7 @@ def main():
         D, ROWB, TILE, LD = d, d * 2, 64 * d * 2, d // 32
         DEFF, KSTEPS, NSTEP, MASKED = deff, deff // 16, 2 * (deff // 32), masked
         unused = [KOFF + i for i in range(LD, 4)] + [VOFF + i for i in range(LD, 4)]  # (no inputs there at LD = 2)
-        clob = "".join(f', "v{i}"' for i in list(range(64, 112)) + unused + list(range(126, 134)))
+        clob = "".join(f', "v{i}"' for i in list(range(64, 112)) + unused + list(range(126, 134)) + (list(range(156, 188)) if FD == 3 else []))
         for T, mf, cvt in (("__bf16", "v_mfma_f32_32x32x16_bf16", cvt_bf16), ("_Float16", "v_mfma_f32_32x32x16_f16", cvt_f16)):
             lines = gen_block(mf, cvt)
             accs, offs = operands(d // 32, d // 16, LD)

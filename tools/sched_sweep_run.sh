@@ -9,5 +9,5 @@ for f in tools/bin/libfa_cyc_*.so; do
 done
 echo "== interleaved A/B" >> $OUT
 PLAIN=$(ls tools/bin/libfa_*.so | grep -v cyc_)
-timeout -k 10 400 python tools/ab_interleaved.py --rounds 5 --shapes c2,s2048,c3 $PLAIN 2>&1 | grep -v amdgpu.ids >> $OUT
+timeout -k 10 400 python tools/ab_interleaved.py --rounds 5 --shapes c2,s2048c,d64,d64c,d96 $PLAIN 2>&1 | grep -v amdgpu.ids >> $OUT
 cat $OUT
