@@ -497,6 +497,15 @@ int fa_debug_read_timing(unsigned long long *dst, int n_wg) {
     return hipMemcpyFromSymbol(dst, HIP_SYMBOL(fa::fa_timing_buf), sizeof(unsigned long long) * 32 * n_wg) == hipSuccess ? 0 : -1;
 }
 #endif
+#ifdef FA_F8_DEBUG
+// developer-only: read and clear the fp8 block-run counters (see fa_fwd_kernel_fp8.h)
+int fa_debug_read_f8(unsigned long long *dst) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(dst, HIP_SYMBOL(fa::fa_f8_dbg), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(fa::fa_f8_dbg), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#endif
 #ifdef FA_CYCLES
 // developer-only: copy the fast-loop cycle stamps of the last fwd_kernel_w64 launch (see fa_fwd_kernel_w64.h) to the host
 int fa_debug_read_cycles(unsigned long long *dst) {

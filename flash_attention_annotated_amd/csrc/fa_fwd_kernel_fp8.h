@@ -20,8 +20,12 @@
 //     is key 32 h + 16 beta + i, so the packed probabilities are the PV product's B operand in natural key order.
 //   * K/V tiles arrive by buffer_load_dwordx4 ... lds through raw buffer descriptors: rows past the end of the sequence read
 //     as zeros (no clamping anywhere in this kernel).
-// Numerics: P' = exp2(s c - m c + OFF) with OFF = 5 and stale-max threshold THR = 3 (P' <= 2^8 < 448 = e4m3 max); l carries
-// 2^OFF as well and it cancels in O / l; LSE = m scale + log(l) - OFF ln 2.
+// Numerics: P' = exp2(s c - m c + OFF) with OFF = 4 and stale-max threshold THR = 4 (P' <= 2^8 < 448 = e4m3 max); l carries
+// 2^OFF as well and it cancels in O / l; LSE = m scale + log(l) - OFF ln 2.  (Round 2 ran OFF 5 / THR 3: on N(0,1) data a row's
+// maximum outgrows its first tile's by more than 2^3 in ~4 % of the rows, i.e. nearly every wave left the generated block 4 - 5
+// times per sweep -- counted with -DFA_F8_DEBUG, tools/f8_debug.py -- and every exit stalls the workgroup's other waves at the
+// tile barrier: 11 - 16 % of the kernel.  At THR 4 that is 0.5 exits per wave; probabilities below 2^-13 of the row's stale
+// maximum now flush to zero instead of 2^-14, against the 2^-9 of an unshifted e4m3 P as the reference's oracle rounds it.)
 #pragma once
 
 #include "fa_fwd_kernel_w64.h"
@@ -31,15 +35,19 @@ typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
 typedef int i32x2_t __attribute__((ext_vector_type(2)));
 }
 
+#ifdef FA_LOOP_FP8_GEN_HEADER  /* developer-only: a timing-ablation variant of the generated loop */
+#include FA_LOOP_FP8_GEN_HEADER
+#else
 #include "fa_fwd_loop_fp8_gen.h"
+#endif
 
 namespace fa {
 
 #ifndef FA_FP8_OFF
-#define FA_FP8_OFF 5
+#define FA_FP8_OFF 4
 #endif
 #ifndef FA_FP8_THR
-#define FA_FP8_THR 3
+#define FA_FP8_THR 4
 #endif
 
 __device__ __forceinline__ int swz8(int row) { return (row & 6) ^ ((row >> 3) & 1); }
@@ -71,6 +79,10 @@ __device__ __forceinline__ void dma_tile_f8(uint32_t lds, u32x4 desc, uint32_t s
                  "s_mov_b32 m0, %0"
                  : "=&s"(keep) : "s"(desc), "s"(lds), "s"(soff), "v"(voff[0]), "v"(voff[1]) : "memory");
 }
+
+#ifdef FA_F8_DEBUG  /* developer-only (tools/f8_debug.py): [0] runs of the generated block, [1] tiles they completed, [2] runs ended by pend, [3] by tripb */
+__device__ unsigned long long fa_f8_dbg[8];
+#endif
 
 __global__ __launch_bounds__(256, 1) void fwd_kernel_fp8(const KParams p) {
     constexpr int D = 128;
@@ -463,6 +475,14 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_fp8(const KParams p) {
                              (uint32_t)(BLOCK_N * k_rs), (uint32_t)(BLOCK_N * v_rs), lds0, lds_wave, i % 3, count, done,
                              pend, tripb);
             i += done;
+#ifdef FA_F8_DEBUG
+            if (lane == 0) {
+                atomicAdd(&fa_f8_dbg[0], 1ull);
+                atomicAdd(&fa_f8_dbg[1], (unsigned long long)done);
+                if (pend != 0) atomicAdd(&fa_f8_dbg[2], 1ull);
+                if (tripb != 0) atomicAdd(&fa_f8_dbg[3], 1ull);
+            }
+#endif
             if (phantom) l_a = l_a_saved;
             if (pend != 0) rescale(oa, ala);
             (void)tripb;  // q-block B's new max is taken at the top of the next iteration (or by the generic tile)

@@ -13,6 +13,7 @@ SHAPES = {  # name: (b, s, h, d, causal, dtype)
     "s4096": (4, 4096, 16, 128, False), "d64": (2, 8192, 32, 64, False), "d64c": (2, 8192, 32, 64, True),
     "d96": (2, 8192, 21, 96, False), "d256": (2, 8192, 8, 256, False), "d256c": (2, 8192, 8, 256, True),
     "d192": (2, 8192, 10, 192, False), "d160": (2, 8192, 12, 160, False),
+    "c5": (4, 8192, 16, 128, False), "c5c": (4, 8192, 16, 128, True),   # fp8 e4m3 inputs (FA3 surface)
 }
 args = sys.argv[1:]
 rounds, shapes = 5, ["c2"]
@@ -41,20 +42,26 @@ for sh in shapes:
     b, s, h, d, causal = SHAPES[sh]
     q, k, v = (torch.randn(b, s, h, d, device="cuda", dtype=torch.bfloat16) for _ in range(3))
     fl = 4 * b * h * s * s * d / (2 if causal else 1)
+    if sh.startswith("c5"):
+        from flash_attention_annotated_amd import hopper_interface as fa3
+        q, k, v = (x.to(torch.float8_e4m3fn) for x in (q, k, v))
+        run = lambda: fa3.flash_attn_func(q, k, v, causal=causal, return_attn_probs=True)
+    else:
+        run = lambda: fa.flash_attn_func(q, k, v, causal=causal, return_attn_probs=True)
     res = {n: [] for n in libs}
     for n in libs:   # warm up (clock, caches, lazy module load)
         _lib._lib = handles[n]
-        for _ in range(10): fa.flash_attn_func(q, k, v, causal=causal)
+        for _ in range(10): run()
     torch.cuda.synchronize()
     for r in range(rounds):
         for n in libs:
             _lib._lib = handles[n]
-            res[n].append(t(lambda: fa.flash_attn_func(q, k, v, causal=causal)))
+            res[n].append(t(run))
     outs = {}
     for n in libs:   # the builds must agree (schedule variants are bit-identical by construction)
         _lib._lib = handles[n]
-        o, lse, _ = fa.flash_attn_func(q, k, v, causal=causal, return_attn_probs=True)
-        outs[n] = (o.float(), lse.float())
+        r = run()
+        outs[n] = (r[0].float(), r[1].float())
     for n in libs[1:]:
         do = (outs[n][0] - outs[libs[0]][0]).abs().max().item()
         dl = (outs[n][1] - outs[libs[0]][1]).abs().max().item()

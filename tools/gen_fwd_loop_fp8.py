@@ -44,6 +44,17 @@ MCA, MCB, LA, LB0, MA, MB = 184, 185, 186, 187, 188, 189
 T0, T1, T2, T3, NXA0, NXA1, NXB0, NXB1 = 190, 191, 192, 193, 194, 195, 196, 197
 LB1, ONE, MAT, MBT, ALA, KBASE, VBASE, PSA0, PSA1, LAS, STB = 198, 199, 200, 201, 202, 203, 204, 205, 206, 207, 208
 MFMA = "v_mfma_scale_f32_32x32x64_f8f6f4"
+# developer-only timing ablations (results are WRONG when non-zero; `--ablate N --out path`, never committed):
+# 1 no LDS-DMA, 2 no guard exits, 4 no max look-ahead, 8 no softmax VALU, 16 no barrier, 32 no LDS fragment reads
+ABLATE = 0
+# ORDER: where a slice's LDS fragment fetch and its wait sit (2 = the fetch as in 1, the wait as in 0).  0 (round 2): fetch in front of the slice, wait right in front of the
+# MFMA; 1 (round 3, what the bf16 loop measured, profiles/r3_sched_sweep*.txt): the fetch right behind MFMA A and the wait for
+# the NEXT slice's fragment right behind MFMA B -- LDS / wait instructions issue for free in the shadow of an MFMA, anywhere
+# else they take VALU issue slots of a loop that is VALU-bound.
+ORDER = 1
+# EXPMIX: 0 = a quad's 4 fma, then its 4 exp, then its 2 packs; 1 = the two pairs of a quad staggered (fma fma exp exp of pair 0 run
+# beside fma fma of pair 1, ...) so that transcendental and plain VALU instructions alternate
+EXPMIX = 1
 
 
 def v(i, n=1):
@@ -66,11 +77,15 @@ class Emitter:
         self.lines.append(f"{name}:")
 
     def ds_k(self, dst, st, off, tag):
+        if ABLATE & 32:
+            return
         for e_ in range(2):
             self.e(f"ds_read_b128 {v(dst + 4 * e_, 4)}, {v(KA + 2 * st + e_)} offset:{off}")
             self.lds_q.append(tag)
 
     def ds_v(self, dst, db, off, tag):
+        if ABLATE & 32:
+            return
         for t in range(4):
             self.e(f"ds_read_b64_tr_b8 {v(dst + 2 * t, 2)}, {v(VA + 2 * db + (t & 1))} offset:{off + 1024 * t}")
             self.lds_q.append(tag)
@@ -97,20 +112,22 @@ def pair(E, s0, mc, pdst, pidx, sum0, sum1):
 
 def pair2(E, s0, mc, pdst, pidx, sum0, sum1):
     """two pairs interleaved (exp results are consumed two instructions later: transcendental forwarding rule)"""
-    for k in range(2):
-        t0, t1 = (T0, T1) if k == 0 else (T2, T3)
-        E.e(f"v_fma_f32 {v(t0)}, {v(s0 + 2 * k)}, %[csc], -{v(mc)}")
-        E.e(f"v_fma_f32 {v(t1)}, {v(s0 + 2 * k + 1)}, %[csc], -{v(mc)}")
-    for k in range(2):
-        t0, t1 = (T0, T1) if k == 0 else (T2, T3)
-        E.e(f"v_exp_f32 {v(t0)}, {v(t0)}")
-        E.e(f"v_exp_f32 {v(t1)}, {v(t1)}")
-    for k in range(2):
-        t0, t1 = (T0, T1) if k == 0 else (T2, T3)
-        E.e(f"v_add_f32 {v(sum0)}, {v(sum0)}, {v(t0)}")
-        E.e(f"v_add_f32 {v(sum1)}, {v(sum1)}, {v(t1)}")
+    if ABLATE & 8:
+        return
+    T = [(T0, T1), (T2, T3)]
+    fma = lambda k: [f"v_fma_f32 {v(T[k][0])}, {v(s0 + 2 * k)}, %[csc], -{v(mc)}", f"v_fma_f32 {v(T[k][1])}, {v(s0 + 2 * k + 1)}, %[csc], -{v(mc)}"]
+    exp = lambda k: [f"v_exp_f32 {v(T[k][0])}, {v(T[k][0])}", f"v_exp_f32 {v(T[k][1])}, {v(T[k][1])}"]
+    def tail(k):
         p = pidx + k
-        E.e(f"v_cvt_pk_fp8_f32 {v(pdst + p // 2)}, {v(t0)}, {v(t1)}" + (" op_sel:[0,0,1]" if p & 1 else ""))
+        return [f"v_add_f32 {v(sum0)}, {v(sum0)}, {v(T[k][0])}", f"v_add_f32 {v(sum1)}, {v(sum1)}, {v(T[k][1])}",
+                f"v_cvt_pk_fp8_f32 {v(pdst + p // 2)}, {v(T[k][0])}, {v(T[k][1])}" + (" op_sel:[0,0,1]" if p & 1 else "")]
+    if EXPMIX == 0:
+        seq = fma(0) + fma(1) + exp(0) + exp(1) + tail(0) + tail(1)
+    else:  # transcendental and plain instructions alternate
+        f0, f1, e0, e1, t0, t1 = fma(0), fma(1), exp(0), exp(1), tail(0), tail(1)
+        seq = [f0[0], f0[1], e0[0], f1[0], e0[1], f1[1], e1[0], t0[0], e1[1], t0[1], t0[2], t1[0], t1[1], t1[2]]
+    for ins in seq:
+        E.e(ins)
 
 
 def gen_tile(E, slot, uid):
@@ -130,23 +147,30 @@ def gen_tile(E, slot, uid):
         beta, st = q >> 1, q & 1
         # fragments one slice ahead (a slice is ~300 cycles of softmax VALU; the first K fragment of a tile is fetched by its
         # predecessor / the entry)
-        if q + 1 < 4:
-            E.ds_k(kf(q + 1), (q + 1) & 1, k_off + 2048 * ((q + 1) >> 1), ("k", uid, q + 1))
-        else:
-            E.ds_v(vf(0), 0, v_off, ("v", uid, 0))
+        def fetch1():
+            if q + 1 < 4:
+                E.ds_k(kf(q + 1), (q + 1) & 1, k_off + 2048 * ((q + 1) >> 1), ("k", uid, q + 1))
+            else:
+                E.ds_v(vf(0), 0, v_off, ("v", uid, 0))
+        if ORDER == 0:
+            fetch1()
         if q == 0:
             E.e(f"s_add_u32 m0, %[lds_wave], {kdst}")
-        E.wait_for(("k", uid, q))
+        E.wait_for(("k", uid, q))     # (ORDER 1: a no-op, the previous slice waited behind its MFMA B; kept for the tile's first slice)
         c_a = "0" if st == 0 else v(SA + 16 * beta, 16)
         c_b = "0" if st == 0 else v(sb_nxt + 16 * beta, 16)
         E.e(f"{MFMA} {v(SA + 16 * beta, 16)}, {v(kf(q), 8)}, %[qa{st}], {c_a}, {v(ONE)}, {v(ONE)} op_sel_hi:[0,0,0]")
-        if q < LD:
+        if ORDER >= 1:
+            fetch1()
+        if q < LD and not (ABLATE & 1):
             E.e(f"buffer_load_dwordx4 {v(KOFF + q)}, %[kdesc], %[ktile] offen offset:{1024 * q} lds")
         pair2(E, sb_cur + 8 * q, MCB, PB, 4 * q, LB0, LB1)
         E.e(f"{MFMA} {v(sb_nxt + 16 * beta, 16)}, {v(kf(q), 8)}, %[qb{st}], {c_b}, {v(ONE)}, {v(ONE)} op_sel_hi:[0,0,0]")
+        if ORDER == 1:
+            E.wait_for(("k", uid, q + 1) if q + 1 < 4 else ("v", uid, 0))
         pair2(E, sb_cur + 8 * q + 4, MCB, PB, 4 * q + 2, LB0, LB1)
         # look-ahead max of S_A(n+1), block 0 (complete since slice 1: >= 30 instructions ago when read in slices 2, 3)
-        if q >= 2:
+        if q >= 2 and not (ABLATE & 4):
             for g in range(2):
                 i = (q - 2) * 8 + 4 * g
                 seed = v(MA) if (q == 2) else v(NXA0 + g)
@@ -157,23 +181,37 @@ def gen_tile(E, slot, uid):
     E.e(f"v_mov_b32 {v(PSA0)}, 0")
     E.e(f"v_mov_b32 {v(PSA1)}, 0")
     for db in range(4):
-        if db + 1 < 4:
-            E.ds_v(vf(db + 1), db + 1, v_off, ("v", uid, db + 1))
-        else:
+        def fetch2():
+            if db + 1 < 4:
+                E.ds_v(vf(db + 1), db + 1, v_off, ("v", uid, db + 1))
+        def tile_barrier():
             # tile barrier in front of the last PV pair: every K/V read of this tile has been issued and is waited for here;
             # the DMA pieces issued one tile ago (all but this tile's 2 LD youngest) have landed.  Behind it the first K
             # fragment of the next tile is fetched under the last PV MFMAs.
             E.e(f"s_waitcnt vmcnt({2 * LD}) lgkmcnt(0)")
             E.lds_q = []
-            E.e("s_barrier")
-            E.ds_k(kf(0), 0, ((slot + 2) % 3) * TILE, ("k", uid + 1, 0))
+            if not (ABLATE & 16):
+                E.e("s_barrier")
+        if ORDER == 0:
+            if db + 1 < 4:
+                fetch2()
+            else:
+                tile_barrier()
+                E.ds_k(kf(0), 0, ((slot + 2) % 3) * TILE, ("k", uid + 1, 0))
+        elif db == 3:
+            tile_barrier()
         if db == 0:
             E.e(f"s_add_u32 m0, %[lds_wave], {vdst}")
         E.wait_for(("v", uid, db))
         E.e(f"{MFMA} %[oa{db}], {v(vf(db), 8)}, {v(pa_cur, 8)}, %[oa{db}], {v(ONE)}, {v(ONE)} op_sel_hi:[0,0,0]")
-        if db < LD:
+        if ORDER >= 1:
+            if db + 1 < 4:
+                fetch2()
+            else:
+                E.ds_k(kf(0), 0, ((slot + 2) % 3) * TILE, ("k", uid + 1, 0))
+        if db < LD and not (ABLATE & 1):
             E.e(f"buffer_load_dwordx4 {v(VOFF + db)}, %[vdesc], %[vtile] offen offset:{1024 * db} lds")
-        if db == 0:
+        if db == 0 and not (ABLATE & 6):
             # look-ahead max of S_A(n+1), block 1 (its last MFMA: slice 3 of phase 1, > 40 instructions ago), then the decision
             for g in range(2):
                 i = 16 + 8 * g
@@ -188,13 +226,16 @@ def gen_tile(E, slot, uid):
             E.label(f".Lf8_back_a{uid % 6}_%=")
         pair2(E, SA + 8 * db, MCA, pa_nxt, 4 * db, PSA0, PSA1)
         E.e(f"{MFMA} %[ob{db}], {v(vf(db), 8)}, {v(PB, 8)}, %[ob{db}], {v(ONE)}, {v(ONE)} op_sel_hi:[0,0,0]")
+        if ORDER == 1 and db + 1 < 4:
+            E.wait_for(("v", uid, db + 1))
         pair2(E, SA + 8 * db + 4, MCA, pa_nxt, 4 * db + 2, PSA0, PSA1)
         # look-ahead max of S_B(n+1) (complete since the end of phase 1)
-        for g in range(2):
-            i = 8 * db + 4 * g
-            seed = v(MB) if db == 0 else v(NXB0 + g)
-            E.e(f"v_max3_f32 {v(NXB0 + g)}, {v(sb_nxt + i)}, {v(sb_nxt + i + 1)}, {seed}")
-            E.e(f"v_max3_f32 {v(NXB0 + g)}, {v(sb_nxt + i + 2)}, {v(sb_nxt + i + 3)}, {v(NXB0 + g)}")
+        if not (ABLATE & 4):
+            for g in range(2):
+                i = 8 * db + 4 * g
+                seed = v(MB) if db == 0 else v(NXB0 + g)
+                E.e(f"v_max3_f32 {v(NXB0 + g)}, {v(sb_nxt + i)}, {v(sb_nxt + i + 1)}, {seed}")
+                E.e(f"v_max3_f32 {v(NXB0 + g)}, {v(sb_nxt + i + 2)}, {v(sb_nxt + i + 3)}, {v(NXB0 + g)}")
     E.e("s_add_u32 %[vtile], %[vtile], %[vstep]")
     # ---- tile end: l_a, B's decision, exits ----
     E.e(f"v_max_f32 {v(NXB0)}, {v(NXB0)}, {v(NXB1)}")
@@ -205,7 +246,8 @@ def gen_tile(E, slot, uid):
     E.e("s_add_u32 %[done], %[done], 1")
     E.e("s_or_b64 vcc, vcc, %[pend]")
     E.e("s_sub_u32 %[count], %[count], 1")
-    E.e(f"s_cbranch_vccnz .Lf8_tripb_%=")
+    if not (ABLATE & 6):
+        E.e(f"s_cbranch_vccnz .Lf8_tripb_%=")
     E.e("s_cmp_eq_u32 %[count], 0")
     E.e(f"s_cbranch_scc1 .Lf8_exit_%=")
 
@@ -262,7 +304,7 @@ def gen_block():
             E.e(f"s_branch .Lf8_t0_{u}")
     # ---- rare: a row of q-block A outgrew its stale max (taken right after the look-ahead, before any score of S_A(n+1) is
     # exponentiated).  New max for every row, alpha for l_a now and for O_A at the caller (pend), then back. ----
-    for pos in range(6):
+    for pos in range(6 if not (ABLATE & 6) else 0):
         E.label(f".Lf8_rare_a{pos}_{u}")
         E.e("s_nop 1")
         E.e(f"v_permlane32_swap_b32 {v(NXA0)}, {v(NXA1)}")
@@ -366,12 +408,18 @@ def render(lines):
 
 
 def main():
+    global ABLATE, ORDER, EXPMIX
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     path = os.path.join(root, "flash_attention_annotated_amd", "csrc", "fa_fwd_loop_fp8_gen.h")
+    for name in ("ablate", "order", "expmix"):   # developer-only variants (with --out)
+        if f"--{name}" in sys.argv:
+            globals()[name.upper()] = int(sys.argv[sys.argv.index(f"--{name}") + 1])
     clob = "".join(f', "v{i}"' for i in list(range(0, 152)) + list(range(168, 180)) + list(range(190, 200)) + [205, 206])
     text = HEADER % {"body": render(gen_block()), "clobbers": clob, "vregion": 3 * TILE}
     if "--check" in sys.argv:
         sys.exit(0 if os.path.exists(path) and open(path).read() == text else 1)
+    if "--out" in sys.argv:
+        path = sys.argv[sys.argv.index("--out") + 1]
     open(path, "w").write(text)
     print(f"wrote {path}: {text.count(chr(10))} lines")
 
