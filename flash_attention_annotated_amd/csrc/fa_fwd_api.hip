@@ -7,6 +7,7 @@
 #include "fa_fwd_kernel.h"
 #include "fa_fwd_kernel_w64.h"
 #include "fa_fwd_kernel_fp8.h"
+#include "fa_fwd_kernel_d256.h"
 
 #include <algorithm>
 #include <atomic>
@@ -440,6 +441,27 @@ int launch_w64(const fa::KParams &kp, hipStream_t stream) {
     return FA_OK;
 }
 
+// head dims 129 .. 256, plain features: 4 waves x 32 rows around the generated loop FastLoop256 (fa_fwd_kernel_d256.h)
+template <typename T, int DEFF>
+int launch_d256(const fa::KParams &kp, hipStream_t stream) {
+    constexpr int smem = fa::smem_bytes_d256();
+    auto kernel = fa::fwd_kernel_d256<T, DEFF>;
+    static std::atomic<uint64_t> attr_set{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = uint64_t(1) << (dev & 63);
+    if (!(attr_set.load(std::memory_order_acquire) & bit)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) {
+            (void)hipGetLastError();
+            return FA_ERR_LAUNCH;
+        }
+        attr_set.fetch_or(bit, std::memory_order_release);
+    }
+    hipLaunchKernelGGL(kernel, dim3(kp.grid), dim3(256), smem, stream, kp);
+    if (hipGetLastError() != hipSuccess) return FA_ERR_LAUNCH;
+    return FA_OK;
+}
+
 template <typename T, int D>
 int dispatch_variant(const fa::KParams &kp, bool softcap, int variant, hipStream_t stream) {
     // variant 0/3: 4 waves x 64 rows, one wave per SIMD, software-pipelined (fa_fwd_kernel_w64.h) -- the default
@@ -451,6 +473,14 @@ int dispatch_variant(const fa::KParams &kp, bool softcap, int variant, hipStream
         else return launch<T, D, 8, false, true>(kp, stream);
     }
     if constexpr (D == 256) {
+        // round 3: the plain problems (dense / varlen, causal / windows, GQA) run the generated-loop kernel; softcap, ALiBi,
+        // paged caches, split-KV and the short-q / explicit shapes keep the compiler-scheduled one
+        if ((variant == 0 || variant == 3) && !softcap && !kp.alibi && !kp.block_table && kp.num_splits <= 1) {
+            // head-dim tiles 160 / 192 / 256 (hopper/tile_size.h:20-45): the zero padding is neither multiplied nor accumulated
+            if (kp.d <= 160) return launch_d256<T, 160>(kp, stream);
+            if (kp.d <= 192) return launch_d256<T, 192>(kp, stream);
+            return launch_d256<T, 256>(kp, stream);
+        }
         // (a DEFF = 192 instantiation -- 12 + 12 instead of 16 + 16 MFMAs per 32-key block -- was measured at exactly the
         //  per-workgroup time of the 256 one, tools/hdim_bench.py: this shape is bound by its register-staged K/V rows, which
         //  stay 512 B wide, not by the matrix pipe; head dims 129..192 therefore keep the 256 instantiation)

@@ -185,6 +185,57 @@ def test_head_dims(d, causal):
     _check(out, out_ref, out_pt, f"d={d}")
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("d", [160, 192, 256])
+@pytest.mark.parametrize("sq,sk,causal,window", [(1024, 1024, False, (-1, -1)), (1024, 1024, True, (-1, -1)),
+                                                 (777, 1301, True, (-1, -1)), (1301, 777, False, (-1, -1)),
+                                                 (1024, 1536, False, (300, 0)), (900, 1100, False, (257, 130))])
+def test_head_dim_tile_256(sq, sk, causal, window, d, dtype):
+    """Head dims 129 .. 256 on their own kernel (fa_fwd_kernel_d256.h: 4 waves x 32 rows around the generated loop FastLoop256):
+    sweeps long enough that the generated block runs many tiles, entered and left at masks (causal diagonal, window edges,
+    sequence tails), GQA 4/2, both 16-bit types; LSE included."""
+    fa = _api()
+    torch.manual_seed(sq + sk + d)
+    q = torch.randn(2, sq, 4, d, dtype=dtype)
+    k = torch.randn(2, sk, 2, d, dtype=dtype)
+    v = torch.randn(2, sk, 2, d, dtype=dtype)
+    out, lse, _ = fa.flash_attn_func(q.to(DEV), k.to(DEV), v.to(DEV), causal=causal, window_size=window, return_attn_probs=True)
+    ref_window = (window[0], sk) if (window[0] >= 0 and window[1] < 0) else window
+    out_ref, out_pt, lse_ref = _dense_ref(q, k, v, causal=causal, window_size=ref_window)
+    _check(out, out_ref, out_pt, f"d={d} {sq}x{sk} causal={causal} window={window}")
+    _check_lse(lse, lse_ref)
+
+
+def test_head_dim_tile_256_varlen_and_forced_trip():
+    """The d256 kernel on a ragged batch (cu_seqlens, lengths 1 .. 900), and its guard: a key that dominates one row late in
+    the sweep makes the partial row sums of the generated block overflow the stale max (the block is left, P redone from the
+    kept scores with a fresh max, O rescaled)."""
+    fa = _api()
+    torch.manual_seed(77)
+    d, h, hk = 192, 4, 2
+    lens = [900, 1, 333, 64, 517]
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32)
+    tot = int(cu[-1])
+    q = torch.randn(tot, h, d, dtype=torch.bfloat16)
+    k = torch.randn(tot, hk, d, dtype=torch.bfloat16)
+    v = torch.randn(tot, hk, d, dtype=torch.bfloat16)
+    out = fa.flash_attn_varlen_func(q.to(DEV), k.to(DEV), v.to(DEV), cu.to(DEV), cu.to(DEV), max(lens), max(lens), causal=True)
+    ref, _ = oracle.attention_varlen_ref(q, k, v, cu, cu, causal=True)
+    pt, _ = oracle.attention_varlen_ref(q, k, v, cu, cu, causal=True, upcast=False, reorder_ops=True)
+    _check(out, ref, pt, "d192 varlen causal")
+    # forced trip: rows 40 (wave 1) and 300 meet their dominant key in tiles 9 and 14 of a 1024-key sweep
+    sq, sk, d = 512, 1024, 256
+    q = torch.randn(1, sq, 2, d, dtype=torch.bfloat16)
+    k = torch.randn(1, sk, 2, d, dtype=torch.bfloat16)
+    v = torch.randn(1, sk, 2, d, dtype=torch.bfloat16)
+    k[0, 600, 0] = q[0, 40, 0] * 3.0
+    k[0, 950, 1] = q[0, 300, 1] * 3.0
+    out, lse, _ = fa.flash_attn_func(q.to(DEV), k.to(DEV), v.to(DEV), return_attn_probs=True)
+    out_ref, out_pt, lse_ref = _dense_ref(q, k, v)
+    _check(out, out_ref, out_pt, "d256 forced guard trip")
+    _check_lse(lse, lse_ref, tol=5e-3)
+
+
 @pytest.mark.parametrize("d", [64, 128])
 @pytest.mark.parametrize("window", [(300, 0), (256, 100), (700, -1), (130, 64)])
 @pytest.mark.parametrize("sq,sk", [(1536, 1536), (1200, 1700)])

@@ -10,7 +10,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("gen", ["gen_fwd_loop.py", "gen_fwd_loop_fp8.py", "gen_bwd_loop.py", "gen_bwd_dq_loop.py"])
+@pytest.mark.parametrize("gen", ["gen_fwd_loop.py", "gen_fwd_loop_fp8.py", "gen_fwd_loop_d256.py", "gen_bwd_loop.py",
+                                 "gen_bwd_dq_loop.py"])
 def test_generated_header_is_current(gen):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", gen), "--check"], capture_output=True, text=True)
     assert r.returncode == 0, f"run `python tools/{gen}` and commit the header"
