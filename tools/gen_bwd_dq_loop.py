@@ -29,6 +29,9 @@ VREG = NSLOT * TILE          # V tiles behind the K tiles
 KSTEPS = D // 16
 NSTEP = 2 * (D // 32)
 LD = 4
+# FETCH_AFTER: 1 = a step's LDS fragment fetches sit right behind its first MFMA (free in the MFMA's shadow:
+# profiles/r3_sched_sweep*.txt), 0 = in front of the step (round 2)
+FETCH_AFTER = 1
 
 # ---- arch VGPRs ----
 SET = (0, 64)                # per half kb: S nb0, S nb1, dP nb0, dP nb1 (16 each)
@@ -135,11 +138,14 @@ def group_sdp(E, slot, kb, uid, valu_kb, dma_slot, nxt):
     if dma_slot is not None:
         E.e(f"s_add_u32 m0, %[lds_wave], {dma_slot * TILE}")
     for ks in range(KSTEPS):
-        if ks + 2 < KSTEPS:
-            E.row_frag(KR, ks + 2, ks + 2, kb_off, ("k", uid, ks + 2))
-            E.row_frag(VR, ks + 2, ks + 2, vb_off, ("v", uid, ks + 2))
-        elif nxt[0] != "row":
-            fetch_first(E, nxt, ks + 2 - KSTEPS)
+        def fetch():
+            if ks + 2 < KSTEPS:
+                E.row_frag(KR, ks + 2, ks + 2, kb_off, ("k", uid, ks + 2))
+                E.row_frag(VR, ks + 2, ks + 2, vb_off, ("v", uid, ks + 2))
+            elif nxt[0] != "row":
+                fetch_first(E, nxt, ks + 2 - KSTEPS)
+        if not FETCH_AFTER:
+            fetch()
         if dma_slot is not None and ks == LD:
             E.e(f"s_add_u32 m0, %[lds_wave], {VREG + dma_slot * TILE}")
         E.wait_for(("k", uid, ks))
@@ -164,6 +170,8 @@ def group_sdp(E, slot, kb, uid, valu_kb, dma_slot, nxt):
                 else:
                     E.e(f"buffer_load_dwordx4 {v(VOFF + i)}, %[vdesc], %[vtile] offen offset:{1024 * i} lds")
         E.e(f"{mf} {v(s0, 16)}, {v(KR + 4 * (ks % 3), 4)}, %[qa{ks}], {c(s0)}")
+        if FETCH_AFTER:
+            fetch()
         pieces(first)
         sl.slot(4 * ks)
         E.e(f"{mf} {v(s1, 16)}, {v(KR + 4 * (ks % 3), 4)}, %[qb{ks}], {c(s1)}")
@@ -206,12 +214,17 @@ def group_dq(E, slot, kb, uid, barrier, nxt):
             # every wave's have, and the first fragments of tile t+1 may be fetched
             E.e("s_waitcnt vmcnt(0)")
             E.e("s_barrier")
-        if t + 2 < NSTEP:
-            E.tr_frag(t + 2, t + 2, off, ("t", uid, t + 2))
-        elif nxt is not None:
-            fetch_first(E, nxt, t + 2 - NSTEP)
+        def fetch():
+            if t + 2 < NSTEP:
+                E.tr_frag(t + 2, t + 2, off, ("t", uid, t + 2))
+            elif nxt is not None:
+                fetch_first(E, nxt, t + 2 - NSTEP)
+        if not FETCH_AFTER:
+            fetch()
         E.wait_for(("t", uid, t))
         E.e(f"{mf} %[dq{db}], {v(KT + 4 * (t % 3), 4)}, {v(DSF[kb] + 4 * st, 4)}, %[dq{db}]")
+        if FETCH_AFTER:
+            fetch()
         E.e(f"{mf} %[dq{D // 32 + db}], {v(KT + 4 * (t % 3), 4)}, {v(DSF[kb] + 8 + 4 * st, 4)}, %[dq{D // 32 + db}]")
 
 

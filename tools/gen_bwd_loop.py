@@ -28,6 +28,9 @@ NSTEP = 2 * (D // 32)
 LD = 4
 # developer-only timing ablations (results are WRONG when non-zero; `--ablate N --out path`, never committed): 8 no pointwise VALU
 ABLATE = 0
+# FETCH_AFTER: 1 = a step's LDS fragment fetches sit right behind its first MFMA (they issue for free in the MFMA's shadow:
+# profiles/r3_sched_sweep*.txt), 0 = in front of the step (round 2)
+FETCH_AFTER = 1
 
 # ---- arch VGPRs ----
 S0, DP0, S1, DP1 = 0, 16, 32, 48
@@ -165,17 +168,21 @@ def group_sdp(E, c, rb, uid, valu, dma):
         E.e(f"s_add_u32 m0, %[lds_wave], {n * TILE}")
     for ks in range(KSTEPS):
         pos = KSTEPS * rb + ks
-        if ks + 2 < KSTEPS:
-            E.row_frag(QR, pos + 2, ks + 2, qb, ("q", uid, rb, ks + 2))
-            E.row_frag(GR, pos + 2, ks + 2, gb, ("g", uid, rb, ks + 2))
-        elif rb == 0:   # first fragments of block 1
-            nk = ks + 2 - KSTEPS
-            E.row_frag(QR, pos + 2, nk, c * TILE + 32 * ROWB, ("q", uid, 1, nk))
-            E.row_frag(GR, pos + 2, nk, (2 + c) * TILE + 32 * ROWB, ("g", uid, 1, nk))
-        else:           # first transposed fragments of group C (block 0)
-            nt = ks + 2 - KSTEPS
-            E.tr_frag(GT, nt, nt, (2 + c) * TILE, ("gt", uid, 0, nt))
-            E.tr_frag(QT, nt, nt, c * TILE, ("qt", uid, 0, nt))
+
+        def fetch():
+            if ks + 2 < KSTEPS:
+                E.row_frag(QR, pos + 2, ks + 2, qb, ("q", uid, rb, ks + 2))
+                E.row_frag(GR, pos + 2, ks + 2, gb, ("g", uid, rb, ks + 2))
+            elif rb == 0:   # first fragments of block 1
+                nk = ks + 2 - KSTEPS
+                E.row_frag(QR, pos + 2, nk, c * TILE + 32 * ROWB, ("q", uid, 1, nk))
+                E.row_frag(GR, pos + 2, nk, (2 + c) * TILE + 32 * ROWB, ("g", uid, 1, nk))
+            else:           # first transposed fragments of group C (block 0)
+                nt = ks + 2 - KSTEPS
+                E.tr_frag(GT, nt, nt, (2 + c) * TILE, ("gt", uid, 0, nt))
+                E.tr_frag(QT, nt, nt, c * TILE, ("qt", uid, 0, nt))
+        if not FETCH_AFTER:
+            fetch()
         if dma and ks == LD:
             E.e(f"s_add_u32 m0, %[lds_wave], {(2 + n) * TILE}")
         E.wait_for(("q", uid, rb, ks))
@@ -201,6 +208,8 @@ def group_sdp(E, c, rb, uid, valu, dma):
                 else:
                     E.e(f"buffer_load_dwordx4 {v(GOFF + i)}, %[gdesc], %[gtile] offen offset:{1024 * i} lds")
         E.e(f"{mf} {v(s, 16)}, {v(QR + 4 * (pos % 3), 4)}, %[kf{ks}], {cs}")
+        if FETCH_AFTER:
+            fetch()
         if dma and ks == 0:
             E.e(f"buffer_load_dword {v(STATR)}, {v(SOFF)}, %[sdesc], %[stile] offen")
         pieces(after_s)
@@ -240,19 +249,24 @@ def group_dvdk(E, c, rb, uid, valu, last, next_uid=None):
             E.e("s_waitcnt lgkmcnt(0)")
             E.wait_all()
             E.e("s_barrier")
-        if t + 2 < NSTEP:
-            E.tr_frag(GT, pos + 2, t + 2, gb, ("gt", uid, rb, t + 2))
-            E.tr_frag(QT, pos + 2, t + 2, qb, ("qt", uid, rb, t + 2))
-        elif rb == 0:
-            nt = t + 2 - NSTEP
-            E.tr_frag(GT, pos + 2, nt, (2 + c) * TILE + 32 * ROWB, ("gt", uid, 1, nt))
-            E.tr_frag(QT, pos + 2, nt, c * TILE + 32 * ROWB, ("qt", uid, 1, nt))
-        else:           # first row fragments of the next tile (buffer n, block 0): ring positions 0, 1
-            nk = t + 2 - NSTEP
-            E.row_frag(QR, nk, nk, n * TILE, ("q", next_uid, 0, nk))
-            E.row_frag(GR, nk, nk, (2 + n) * TILE, ("g", next_uid, 0, nk))
+        def fetch():
+            if t + 2 < NSTEP:
+                E.tr_frag(GT, pos + 2, t + 2, gb, ("gt", uid, rb, t + 2))
+                E.tr_frag(QT, pos + 2, t + 2, qb, ("qt", uid, rb, t + 2))
+            elif rb == 0:
+                nt = t + 2 - NSTEP
+                E.tr_frag(GT, pos + 2, nt, (2 + c) * TILE + 32 * ROWB, ("gt", uid, 1, nt))
+                E.tr_frag(QT, pos + 2, nt, c * TILE + 32 * ROWB, ("qt", uid, 1, nt))
+            else:           # first row fragments of the next tile (buffer n, block 0): ring positions 0, 1
+                nk = t + 2 - NSTEP
+                E.row_frag(QR, nk, nk, n * TILE, ("q", next_uid, 0, nk))
+                E.row_frag(GR, nk, nk, (2 + n) * TILE, ("g", next_uid, 0, nk))
+        if not FETCH_AFTER:
+            fetch()
         E.wait_for(("gt", uid, rb, t))
         E.e(f"{mf} %[dv{db}], {v(GT + 4 * (pos % 3), 4)}, {v(pf + 4 * st, 4)}, %[dv{db}]")
+        if FETCH_AFTER:
+            fetch()
         sl.slot(2 * t)
         E.wait_for(("qt", uid, rb, t))
         E.e(f"{mf} %[dk{db}], {v(QT + 4 * (pos % 3), 4)}, {v(dsf + 4 * st, 4)}, %[dk{db}]")
