@@ -27,7 +27,7 @@ def aligned(t):
 def launch(q, k, v, out, lse, *, varlen, batch, max_seqlen_q, max_seqlen_k, softmax_scale, causal, window_left,
            window_right, softcap, cu_seqlens_q=None, cu_seqlens_k=None, seqused_q=None, seqused_k=None,
            q_descale=None, k_descale=None, v_descale=None, alibi_slopes=None, kv_batch_idx=None, block_table=None, num_splits=1, leftpad_k=None,
-           p_dropout=0.0, rng_state=None, s_dmask=None, fa3_window=False):
+           p_dropout=0.0, rng_state=None, s_dmask=None, fa3_window=False, s_dmask_block_n=0):
     """q/k/v/out: dense (b, s, h, d) or packed (total, h, d) tensors on one GPU, last stride 1, aligned()."""
     lib = _lib.load()
     prm = _lib.new_params()
@@ -73,6 +73,9 @@ def launch(q, k, v, out, lse, *, varlen, batch, max_seqlen_q, max_seqlen_k, soft
     prm.p_dropout = float(p_dropout)
     prm.rng_state, prm.s_dmask = ptr(rng_state), ptr(s_dmask)
     prm.flags = _lib.FA_FLAG_FA3_WINDOW if fa3_window else 0
+    if s_dmask is not None and s_dmask_block_n > 0:  # the reference's sign-encoded layout (b, h, rows, cols), input dtype
+        prm.flags |= _lib.FA_FLAG_SDMASK_SIGNED
+        prm.s_dmask_rows, prm.s_dmask_cols, prm.s_dmask_block_n = s_dmask.shape[-2], s_dmask.shape[-1], int(s_dmask_block_n)
     prm.num_splits = int(num_splits)  # 1 = off (prefill entry points), 0 = library heuristic (decode), N = forced
     if block_table is not None:
         prm.block_table = ptr(block_table)

@@ -14,8 +14,9 @@ LIB_PATH = os.path.join(_HERE, LIB_NAME)
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
-FA_ABI_VERSION = 10
+FA_ABI_VERSION = 11
 FA_FLAG_FA3_WINDOW = 1
+FA_FLAG_SDMASK_SIGNED = 2
 FA_DTYPE_FP16, FA_DTYPE_BF16, FA_DTYPE_FP8_E4M3 = 0, 1, 2
 
 # every symbol include/fa_fwd.h declares (tests check the .so exports all of them)
@@ -106,6 +107,10 @@ class FaFwdParams(ctypes.Structure):
         ("flags", ctypes.c_int32),
         ("rng_state", ctypes.c_void_p),
         ("s_dmask", ctypes.c_void_p),
+        ("s_dmask_rows", ctypes.c_int32),
+        ("s_dmask_cols", ctypes.c_int32),
+        ("s_dmask_block_n", ctypes.c_int32),
+        ("reserved_sdmask", ctypes.c_int32),
     ]
 
 

@@ -184,6 +184,90 @@ __global__ void kvcache_append_kernel(const fa_kvcache_append_params p) {
     }
 }
 
+// ---- sign-encoded S_dmask (FA_FLAG_SDMASK_SIGNED, include/fa_fwd.h): what the reference's CUDA forward returns for
+// return_softmax under dropout (csrc/flash_attn/src/flash_fwd_kernel.h:350-360, 412-422; src/dropout.h:26-33), restated as a
+// pass of its own -- a testing aid there and here, not on the hot path.  One workgroup = 8 query rows of one (batch, head);
+// per row: all scores (fp32 dot products, scaled, + ALiBi, masked) into LDS, the row maximum of every key block of `block_n`
+// keys, their suffix maxima (the running maximum of a sweep from the last block to the first), then
+// exp(score - suffix max of its block), negated where fa_rand8 (the forward's hash) drops the element.
+template <typename T>
+__global__ __launch_bounds__(256) void sdmask_kernel(const fa::KParams p, T *out, int rows_r, int cols_r, int block_n) {
+    extern __shared__ __attribute__((aligned(16))) char smem_[];
+    constexpr int ROWS = 8;
+    const int nrb = (p.seqlen_q + ROWS - 1) / ROWS;
+    const int rb = blockIdx.x % nrb, head = (blockIdx.x / nrb) % p.h, batch = blockIdx.x / (nrb * p.h);
+    const int kv_head = head / p.h_ratio;
+    int sq, sk;
+    int64_t q_base, k_base;
+    if (p.cu_seqlens_q) {
+        const int q0 = p.cu_seqlens_q[batch], k0 = p.cu_seqlens_k[batch];
+        sq = p.seqused_q ? p.seqused_q[batch] : p.cu_seqlens_q[batch + 1] - q0;
+        sk = p.seqused_k ? p.seqused_k[batch] : p.cu_seqlens_k[batch + 1] - k0;
+        q_base = (int64_t)q0 * p.q_row_stride;
+        k_base = (int64_t)k0 * p.k_row_stride;
+    } else {
+        sq = p.seqused_q ? p.seqused_q[batch] : p.seqlen_q;
+        sk = p.seqused_k ? p.seqused_k[batch] : p.seqlen_k;
+        q_base = (int64_t)batch * p.q_batch_stride;
+        k_base = (int64_t)batch * p.k_batch_stride;
+    }
+    if (rb * ROWS >= sq || sk <= 0) return;
+    const T *qp = (const T *)p.q + q_base + (int64_t)head * p.q_head_stride;
+    const T *kp = (const T *)p.k + k_base + (int64_t)kv_head * p.k_head_stride;
+    T *op = out + (((int64_t)batch * p.h + head) * rows_r) * cols_r;
+    const fa::Scales sc = fa::load_scales(p, batch, kv_head);
+    const float alibi = p.alibi ? p.alibi[(int64_t)batch * p.alibi_bs + head] : 0.f;
+    const uint32_t seed_mix = fa::fa_seed_mix(p.rng_state, batch * p.h + head);
+    const int shift = sk - sq;
+    float *qs = (float *)smem_;                // [ROWS][d]
+    float *scs = qs + ROWS * p.d;              // [sk]
+    float *bm = scs + ((sk + 3) & ~3);         // [nblk]
+    const int nblk = (sk + block_n - 1) / block_n;
+    for (int i = threadIdx.x; i < ROWS * p.d; i += 256) {
+        const int r = rb * ROWS + i / p.d;
+        qs[i] = r < sq ? (float)qp[(int64_t)r * p.q_row_stride + i % p.d] : 0.f;
+    }
+    __syncthreads();
+    for (int rr = 0; rr < ROWS; ++rr) {
+        const int row = rb * ROWS + rr;
+        if (row >= sq) break;   // (uniform)
+        const float *qr = qs + rr * p.d;
+        for (int key = threadIdx.x; key < sk; key += 256) {
+            const T *kr = kp + (int64_t)key * p.k_row_stride;
+            float acc = 0.f;
+            for (int c = 0; c < p.d; c += 8) {
+                const uint4 w = *reinterpret_cast<const uint4 *>(kr + c);
+                float x[8];
+                unpack8<T>(w, x);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc += qr[c + e] * x[e];
+            }
+            float sv = acc * sc.scale - alibi * fabsf((float)(row + shift - key));
+            bool vis = true;
+            if (p.window_right >= 0) vis = vis && key <= row + shift + p.window_right;
+            if (p.window_left >= 0) vis = vis && key >= row + shift - p.window_left;
+            scs[key] = vis ? sv : -INFINITY;
+        }
+        __syncthreads();
+        for (int j = threadIdx.x; j < nblk; j += 256) {
+            float m = -INFINITY;
+            for (int key = j * block_n; key < min(sk, (j + 1) * block_n); ++key) m = fmaxf(m, scs[key]);
+            bm[j] = m;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0)
+            for (int j = nblk - 2; j >= 0; --j) bm[j] = fmaxf(bm[j], bm[j + 1]);
+        __syncthreads();
+        for (int key = threadIdx.x; key < sk; key += 256) {
+            const float m = bm[key / block_n];
+            const float pv = (scs[key] == -INFINITY || m == -INFINITY) ? 0.f : __expf(scs[key] - m);
+            const bool keep = fa::fa_rand8(seed_mix, (uint32_t)row, (uint32_t)key) <= (uint32_t)p.drop_thr;
+            op[(int64_t)row * cols_r + key] = (T)(keep ? pv : -pv);
+        }
+        __syncthreads();
+    }
+}
+
 int64_t align256(int64_t x) { return (x + 255) & ~int64_t(255); }
 
 struct Fp8Plan {
@@ -722,6 +806,10 @@ int fa_fwd_validate(const fa_fwd_params *p) {
     } else if (p->s_dmask) {
         return FA_ERR_UNSUPPORTED;  // the randval tensor only exists under dropout
     }
+    if ((p->flags & FA_FLAG_SDMASK_SIGNED) && p->s_dmask) {
+        if (p->s_dmask_rows < p->seqlen_q || p->s_dmask_cols < p->seqlen_k || p->s_dmask_block_n <= 0) return FA_ERR_BAD_SHAPE;
+        if (p->seqlen_k > 32768) return FA_ERR_UNSUPPORTED;  // (one row of scores in LDS)
+    }
     if (p->kv_batch_idx && (p->cu_seqlens_q || fp8)) return FA_ERR_UNSUPPORTED;  // dense 16-bit caches only
     if (p->leftpad_k && (p->block_table || fp8)) return FA_ERR_UNSUPPORTED;  // (:1396 "Paged KV and leftpad_k" not together)
     if (p->block_table) {
@@ -857,7 +945,8 @@ int fa_fwd(const fa_fwd_params *p, void *stream_) {
     kp.drop_thr = p->p_dropout > 0.f ? (int32_t)std::floor(255.0 * (1.0 - (double)p->p_dropout)) : 255;
     kp.rp_dropout = p->p_dropout > 0.f ? 1.f / (1.f - p->p_dropout) : 1.f;
     kp.rng_state = p->rng_state;
-    kp.s_dmask = p->s_dmask;
+    const bool sdmask_signed = (p->flags & FA_FLAG_SDMASK_SIGNED) && p->s_dmask;
+    kp.s_dmask = sdmask_signed ? nullptr : p->s_dmask;
     kp.kv_batch_idx = p->cu_seqlens_q ? nullptr : p->kv_batch_idx;
     kp.block_table = p->block_table;
     kp.bt_bs = (int32_t)p->block_table_batch_stride;
@@ -894,6 +983,27 @@ int fa_fwd(const fa_fwd_params *p, void *stream_) {
     const bool bf16 = p->dtype == FA_DTYPE_BF16 || fp8;  // fp8: out is bf16
     const int st_main = bf16 ? dispatch_hdim<__bf16>(kp, softcap, variant, stream)
                              : dispatch_hdim<_Float16>(kp, softcap, variant, stream);
+    if (st_main == FA_OK && sdmask_signed && !nothing) {
+        const int nrb = (p->seqlen_q + 7) / 8;
+        const int64_t blocks = (int64_t)nrb * p->h * p->b;
+        const int nblk = (p->seqlen_k + p->s_dmask_block_n - 1) / p->s_dmask_block_n;
+        const size_t smem = sizeof(float) * ((size_t)8 * p->d + ((p->seqlen_k + 3) & ~3) + nblk + 4);
+        if (blocks > 0x7fffffff) return FA_ERR_BAD_SHAPE;
+        auto launch_sd = [&](auto tag) -> int {
+            using T = decltype(tag);
+            auto kernel = sdmask_kernel<T>;
+            if (smem > 65536 &&
+                hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
+                (void)hipGetLastError();
+                return FA_ERR_LAUNCH;
+            }
+            hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(256), smem, stream, kp, reinterpret_cast<T *>(p->s_dmask),
+                               p->s_dmask_rows, p->s_dmask_cols, p->s_dmask_block_n);
+            return hipGetLastError() == hipSuccess ? FA_OK : FA_ERR_LAUNCH;
+        };
+        const int st_sd = bf16 ? launch_sd(__bf16{}) : launch_sd(_Float16{});
+        if (st_sd != FA_OK) return st_sd;
+    }
     if (st_main != FA_OK || sp.splits <= 1) return st_main;
     // merge the partial results into the caller's out / softmax_lse
     const int64_t total = (int64_t)p->b * p->seqlen_q * p->h * (p->d / 8);

@@ -62,6 +62,25 @@ def _check_shape(x, name, *shape):
     _check(tuple(x.shape) == tuple(shape), f"{name} must have shape ({', '.join(str(s) for s in shape)})")
 
 
+def _sdmask_block_n(head_dim, is_dropout, is_causal):
+    """kBlockN of the reference's forward for this head dim (flash_attn/flash_attn_interface.py:23-46, the row of a device
+    that is neither sm8x nor sm90 -- what `_get_block_size_n` answers on this GPU): the key-block width behind the running
+    maxima of the returned S_dmask, which tests/test_flash_attn.py:479-526 undoes with the same table."""
+    if head_dim <= 32:
+        return 128
+    if head_dim <= 64:
+        return 128 if not is_dropout else 64
+    if head_dim <= 96:
+        return 64
+    if head_dim <= 128:
+        return 64 if not is_dropout else 32
+    return 64
+
+
+def _round128(x):
+    return (x + 127) // 128 * 128
+
+
 def _check_dropout(p_dropout, return_softmax):
     """csrc/flash_attn/flash_api.cpp:131 (p_dropout < 1) and :428-431 (return_softmax needs dropout)."""
     _check(0.0 <= p_dropout < 1.0, "p_dropout must be in [0, 1)")
@@ -161,9 +180,10 @@ def fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out_: Optional[torch.
 
     with torch.cuda.device(q.device):
         softmax_lse = torch.empty((batch_size, num_heads, seqlen_q), dtype=torch.float32, device=q.device)
-        # return_softmax: the uint8 random values behind the dropout decisions, (b, h, seqlen_q, seqlen_k) -- the
-        # reference's ROCm convention (tests/test_flash_attn_ck.py:34-38: kept iff value <= floor(255 (1 - p)))
-        p = (torch.zeros((batch_size, num_heads, seqlen_q, seqlen_k), dtype=torch.uint8, device=q.device)
+        # return_softmax: S_dmask as the reference's CUDA forward returns it (csrc/flash_attn/flash_api.cpp:436-449):
+        # (b, h, seqlen_q rounded to 128, seqlen_k rounded to 128) in the input dtype, the probabilities relative to the
+        # running maximum of their key block, negative where dropout discards them (include/fa_fwd.h FA_FLAG_SDMASK_SIGNED)
+        p = (torch.zeros((batch_size, num_heads, _round128(seqlen_q), _round128(seqlen_k)), dtype=q_dtype, device=q.device)
              if return_softmax else torch.empty((0,), dtype=q_dtype, device=q.device))
         rng_state = _dropout_state(p_dropout, gen_, q.device)
 
@@ -175,6 +195,7 @@ def fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out_: Optional[torch.
                              window_left=window_size_left, window_right=window_size_right, softcap=softcap,
                              alibi_slopes=alibi, p_dropout=p_dropout, rng_state=rng_state if p_dropout > 0 else None,
                              s_dmask=p if return_softmax else None,
+                             s_dmask_block_n=_sdmask_block_n(head_size, p_dropout > 0, is_causal),
                              # the split heuristic runs whenever there is no dropout, as in mha_fwd (flash_api.cpp:453-456);
                              # it only splits problems whose tiles leave most CUs idle
                              num_splits=0 if p_dropout == 0 else 1)
@@ -259,8 +280,10 @@ def varlen_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out_: Optional
 
     with torch.cuda.device(q.device):
         softmax_lse = torch.empty((num_heads, total_q), dtype=torch.float32, device=q.device)
-        # return_softmax: uint8 random values, (h, total_q, max_seqlen_k) (tests/test_flash_attn_ck.py:40-62)
-        p = (torch.zeros((num_heads, total_q, max_seqlen_k), dtype=torch.uint8, device=q.device)
+        # return_softmax: S_dmask (b, h, max_seqlen_q rounded to 128, max_seqlen_k rounded to 128), each sequence's block
+        # at [i, :, :seqlen_q_i, :seqlen_k_i] (csrc/flash_attn/flash_api.cpp:648-660)
+        p = (torch.zeros((batch_size, num_heads, _round128(max_seqlen_q), _round128(max_seqlen_k)), dtype=q_dtype,
+                         device=q.device)
              if return_softmax else torch.empty((0,), dtype=q_dtype, device=q.device))
         rng_state = _dropout_state(p_dropout, gen_, q.device)
         if zero_tensors:
@@ -275,7 +298,8 @@ def varlen_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out_: Optional
                              window_left=window_size_left, window_right=window_size_right, softcap=softcap,
                              cu_seqlens_q=cu_seqlens_q, cu_seqlens_k=cu_seqlens_k, seqused_k=seqused_k,
                              alibi_slopes=alibi, block_table=block_table_, leftpad_k=leftpad_k_, p_dropout=p_dropout,
-                             rng_state=rng_state if p_dropout > 0 else None, s_dmask=p if return_softmax else None)
+                             rng_state=rng_state if p_dropout > 0 else None, s_dmask=p if return_softmax else None,
+                             s_dmask_block_n=_sdmask_block_n(head_size, p_dropout > 0, is_causal))
             if oc is not out:
                 out.copy_(oc)
         elif total_q > 0:

@@ -71,14 +71,15 @@ def _flash_attn_forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, dropo
 @_register_fake("flash_attn_amd::_flash_attn_forward")
 def _flash_attn_forward_fake(q, k, v, dropout_p, softmax_scale, causal, window_size_left, window_size_right, softcap,
                              alibi_slopes, return_softmax):
-    """reference :109-136 (on HIP the fake `p` is the unrounded (b, h, sq, sk), :130-131)"""
+    """reference :109-136 (the CUDA branch: `p` is (b, h, seqlen_q rounded to 128, seqlen_k rounded to 128), :132-135)"""
     batch_size, seqlen_q, num_heads, _ = q.shape
     seqlen_k = k.shape[1]
     out = torch.empty_like(q)  # (same strides as the real op: flash_attn_2_cuda.fwd allocates empty_like(q))
     softmax_lse = torch.empty((batch_size, num_heads, seqlen_q), dtype=torch.float32, device=q.device)
     p = torch.empty((0,), dtype=q.dtype, device=q.device)
     if return_softmax:
-        p = torch.empty((batch_size, num_heads, seqlen_q, seqlen_k), dtype=torch.uint8, device=q.device)
+        p = torch.empty((batch_size, num_heads, (seqlen_q + 127) // 128 * 128, (seqlen_k + 127) // 128 * 128), dtype=q.dtype,
+                        device=q.device)
     rng_state = torch.empty((2,), dtype=torch.int64, device=q.device)
     return out, softmax_lse, p, rng_state
 
@@ -165,7 +166,8 @@ def _flash_attn_varlen_forward_fake(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seq
     softmax_lse = torch.empty((num_heads, total_q), dtype=torch.float32, device=q.device)
     p = torch.empty((0,), dtype=q.dtype, device=q.device)
     if return_softmax:
-        p = torch.empty((num_heads, q.shape[0], max_seqlen_k), dtype=torch.uint8, device=q.device)
+        p = torch.empty((batch_size, num_heads, (max_seqlen_q + 127) // 128 * 128, (max_seqlen_k + 127) // 128 * 128),
+                        dtype=q.dtype, device=q.device)
     rng_state = torch.empty((2,), dtype=torch.int64, device=q.device)
     return out, softmax_lse, p, rng_state
 

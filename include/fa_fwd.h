@@ -38,9 +38,10 @@
 extern "C" {
 #endif
 
-#define FA_ABI_VERSION 10
+#define FA_ABI_VERSION 11
 
 #define FA_FLAG_FA3_WINDOW 1
+#define FA_FLAG_SDMASK_SIGNED 2   /* s_dmask is the reference's sign-encoded probability tensor (below), not random bytes */
 
 /* element types of q/k/v (o has the same type; fp8 inputs produce bf16 o) */
 enum fa_dtype {
@@ -179,6 +180,16 @@ typedef struct fa_fwd_params {
     int32_t flags;
     const uint64_t *rng_state;
     uint8_t *s_dmask;
+    /* ABI v11 -- FA_FLAG_SDMASK_SIGNED: s_dmask is what the reference's CUDA forward returns for return_softmax
+     * (csrc/flash_attn/src/flash_fwd_kernel.h:350-360, src/dropout.h:26-33; decoded by tests/test_flash_attn.py:411-526):
+     * (b, h, s_dmask_rows, s_dmask_cols) elements of the INPUT dtype, row-major, rows / cols = seqlen_q / seqlen_k rounded up
+     * to 128 (varlen: the max_seqlen's; batch entry i's block at [i, :, 0:seqlen_q_i, 0:seqlen_k_i]).  Element (row, key) =
+     * exp(score - m) with m the maximum of the row's scores over key blocks [key / s_dmask_block_n, last] -- the running
+     * maximum of a sweep that walks the key blocks from the last to the first, as the reference's kernel does -- and a
+     * NEGATIVE sign where dropout discards the element.  s_dmask_block_n = the reference's kBlockN for this head dim
+     * (flash_attn/flash_attn_interface.py:23-46).  Testing aid like the reference's: written by a pass of its own behind the
+     * forward (fa_sdmask in fa_fwd_api.hip), seqlen_k <= 32768. */
+    int32_t s_dmask_rows, s_dmask_cols, s_dmask_block_n, reserved_sdmask;
 } fa_fwd_params;
 
 /* Validate and enqueue the forward on `stream` (a hipStream_t; NULL = default

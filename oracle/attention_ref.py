@@ -196,3 +196,77 @@ def attention_combine_ref(out_partial, lse_partial):
     scale = torch.where(torch.isinf(scale) | torch.isnan(scale), torch.zeros_like(scale), scale)
     out = (scale.unsqueeze(-1) * out_partial).sum(0)
     return out, lse
+
+
+def sdmask_block_size_n(head_dim, is_dropout, is_causal):
+    """The reference forward's key-block width for a head dim on a device that is neither sm8x nor sm90
+    (flash_attn/flash_attn_interface.py:23-46 `_get_block_size_n`): the blocks behind the running maxima of S_dmask."""
+    if head_dim <= 32:
+        return 128
+    if head_dim <= 64:
+        return 128 if not is_dropout else 64
+    if head_dim <= 96:
+        return 64
+    if head_dim <= 128:
+        return 64 if not is_dropout else 32
+    return 64
+
+
+def convert_flash_attn_S_to_softmax(S, seqlen_q, seqlen_k, query_padding_mask, key_padding_mask, causal=False,
+                                    window_size=(-1, -1)):
+    """tests/test_flash_attn.py:411-463: the (b, h, seqlen_q rounded, seqlen_k rounded) tensor `return_softmax` hands back, cut to
+    (b, h, seqlen_q, seqlen_k) with everything the attention does not look at zeroed.  Its sign is the dropout decision
+    (>= 0: kept), its magnitude exp(score - running max of the key block)."""
+    if causal:
+        window_size = (window_size[0], 0)
+    seqlen_q_rounded, seqlen_k_rounded = S.shape[-2:]
+    S_converted = S
+    if window_size[0] >= 0 or window_size[1] >= 0:
+        lm = local_mask(seqlen_q, seqlen_k, window_size, query_padding_mask, key_padding_mask)
+        lm = torch.nn.functional.pad(lm, (0, seqlen_k_rounded - seqlen_k, 0, seqlen_q_rounded - seqlen_q), value=True)
+        S_converted = S_converted.masked_fill(lm, 0.0)
+    seqlen_q_og = query_padding_mask.shape[-1] if query_padding_mask is not None else seqlen_q_rounded
+    if query_padding_mask is not None:
+        qm = torch.nn.functional.pad(query_padding_mask, (0, seqlen_q_rounded - seqlen_q_og))
+        S_converted = S_converted.masked_fill(~qm[:, None, :, None], 0.0)
+    seqlen_k_og = key_padding_mask.shape[-1] if key_padding_mask is not None else seqlen_k
+    if key_padding_mask is not None:
+        km = torch.nn.functional.pad(key_padding_mask, (0, seqlen_k_rounded - seqlen_k_og))
+        S_converted = S_converted.masked_fill(~km[:, None, None, :], 0.0)
+    S_converted = torch.nn.functional.pad(S_converted, (0, 0, 0, seqlen_q_og - seqlen_q_rounded))
+    S_converted = torch.nn.functional.pad(S_converted, (0, seqlen_k_og - seqlen_k_rounded))
+    return S_converted[:, :, :seqlen_q, :seqlen_k]
+
+
+def normalize_flash_attn_S(attn_unnorm, q, k, v, query_padding_mask=None, key_padding_mask=None, attn_bias=None,
+                           is_dropout=False, causal=False, window_size=(-1, -1), block_size_n=None):
+    """tests/test_flash_attn.py:466-526: turns |S_dmask| into the softmax probabilities -- each key block of `block_size_n`
+    keys carries exp(score - m) with m the maximum over its own and all LATER blocks (the reference's sweep runs from the last
+    key block to the first), so a * exp(m - lse) is the probability."""
+    if causal:
+        window_size = (window_size[0], 0)
+    q, k, v = q.float(), k.float(), v.float()
+    _, seqlen_q, _, head_dim = q.shape
+    seqlen_k = k.shape[1]
+    if block_size_n is None:
+        block_size_n = sdmask_block_size_n(head_dim, is_dropout, causal)
+    k = k.repeat_interleave(q.shape[2] // k.shape[2], dim=2)
+    scores = torch.einsum("bthd,bshd->bhts", q / math.sqrt(head_dim), k)
+    if key_padding_mask is not None:
+        scores.masked_fill_(~key_padding_mask[:, None, None, :], float("-inf"))
+    if window_size[0] >= 0 or window_size[1] >= 0:
+        lm = local_mask(seqlen_q, seqlen_k, window_size, query_padding_mask, key_padding_mask)
+        scores.masked_fill_(lm, float("-inf"))
+    if attn_bias is not None:
+        scores = scores + attn_bias.to(dtype=scores.dtype)
+    scores_block = scores.split(block_size_n, dim=-1)
+    lse_block = torch.stack([torch.logsumexp(s, dim=-1) for s in scores_block], dim=-1)
+    lse = torch.logsumexp(lse_block, dim=-1)
+    lse[lse == float("-inf")] = float("inf")
+    scores_max_block = torch.stack([torch.amax(s, dim=-1) for s in scores_block], dim=-1)
+    cummax_block = torch.cummax(scores_max_block.flip(-1), dim=-1).values.flip(-1).unbind(dim=-1)
+    attn_unnorm_block = attn_unnorm.split(block_size_n, dim=-1)
+    attn_norm = torch.cat([a * torch.exp(m - lse)[..., None] for a, m in zip(attn_unnorm_block, cummax_block)], dim=-1)
+    if query_padding_mask is not None:
+        attn_norm.masked_fill_(~query_padding_mask[:, None, :, None], 0.0)
+    return attn_norm.to(dtype=attn_unnorm.dtype)

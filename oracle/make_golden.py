@@ -250,6 +250,53 @@ def main():
     grads["combine_pin"] = {"out_partial": op, "lse_partial": lp, "out": want_o, "lse": want_l}
     print("attention_combine_ref restatement == reference")
 
+    # ---- S_dmask decoders (tests/test_flash_attn.py:411-463 convert_flash_attn_S_to_softmax, :466-526 normalize_flash_attn_S;
+    #      the module needs the GPU extension at import, the two functions are compiled out of its syntax tree).  The block
+    #      width comes from _get_block_size_n, which asks the CUDA device: it is handed in here ---------------------------
+    import math as _math
+    import torch.nn.functional as _F
+    from einops import rearrange as _rearrange
+    path = os.path.join(REF, "tests/test_flash_attn.py")
+    tree = ast.parse(open(path).read(), filename=path)
+    fns = [n for n in tree.body if isinstance(n, ast.FunctionDef)
+           and n.name in ("convert_flash_attn_S_to_softmax", "normalize_flash_attn_S")]
+    assert len(fns) == 2
+    for bn in (32, 64, 128):
+        ns = {"torch": torch, "math": _math, "F": _F, "rearrange": _rearrange,
+              "construct_local_mask": fa2.construct_local_mask, "_get_block_size_n": lambda *a, _bn=bn: _bn}
+        exec(compile(ast.Module(body=fns, type_ignores=[]), path, "exec"), ns)
+        gen = torch.Generator().manual_seed(900 + bn)
+        bq, hq, sq_, sk_, dq_ = 2, 3, 150, 201, 32
+        qx = torch.randn(bq, sq_, hq, dq_, generator=gen).to(torch.bfloat16)
+        kx = torch.randn(bq, sk_, hq, dq_, generator=gen).to(torch.bfloat16)
+        qmx = torch.arange(sq_)[None, :] < torch.tensor([sq_, 97])[:, None]
+        kmx = torch.arange(sk_)[None, :] < torch.tensor([130, sk_])[:, None]
+        S = torch.randn(bq, hq, 256, 256, generator=gen).to(torch.bfloat16)   # signs and magnitudes: any values do
+        for causal, window in ((False, (-1, -1)), (True, (-1, -1)), (False, (40, 17))):
+            want = ns["convert_flash_attn_S_to_softmax"](S, sq_, sk_, qmx, kmx, dq_, True, causal=causal, window_size=window)
+            got = mine.convert_flash_attn_S_to_softmax(S, sq_, sk_, qmx, kmx, causal=causal, window_size=window)
+            assert torch.equal(want, got), ("convert_flash_attn_S_to_softmax", bn, causal, window)
+            want_n = ns["normalize_flash_attn_S"](want.abs(), qx, kx, kx, qmx, kmx, None, True, causal=causal, window_size=window)
+            got_n = mine.normalize_flash_attn_S(got.abs(), qx, kx, kx, qmx, kmx, None, True, causal=causal, window_size=window,
+                                                block_size_n=bn)
+            assert torch.equal(want_n, got_n), ("normalize_flash_attn_S", bn, causal, window)
+    # the block-width table itself (flash_attn/flash_attn_interface.py:23-46), for a device that is neither sm8x nor sm90
+    spec_if = ast.parse(open(os.path.join(REF, "flash_attn/flash_attn_interface.py")).read())
+    fn_bs = [n for n in spec_if.body if isinstance(n, ast.FunctionDef) and n.name == "_get_block_size_n"]
+    class _Cuda:  # (what torch.cuda.get_device_capability answers on gfx950: major 9, minor != 0)
+        @staticmethod
+        def get_device_capability(device=None):
+            return (9, 5)
+    class _Torch:
+        cuda = _Cuda
+    ns_bs = {"torch": _Torch}
+    exec(compile(ast.Module(body=fn_bs, type_ignores=[]), "flash_attn_interface.py", "exec"), ns_bs)
+    for hd in (16, 32, 40, 64, 80, 96, 128, 160, 192, 224, 256):
+        for drop in (False, True):
+            for caus in (False, True):
+                assert ns_bs["_get_block_size_n"]("cuda", hd, drop, caus) == mine.sdmask_block_size_n(hd, drop, caus), (hd, drop, caus)
+    print("S_dmask decoders and block-width table == reference")
+
     # ---- dropout (tests/test_util.py:262-269): with the SAME keep-mask the restatement equals the reference, output
     #      and gradients; the case is kept as a fixture (mask included) for tests/test_oracle.py --------------------
     gen = torch.Generator().manual_seed(4242)

@@ -1,11 +1,15 @@
 """GPU parity tests of attention dropout through the public API.
 
-Modelled on the reference's ROCm tests (tests/test_flash_attn_ck.py:78-171, 183-300, 330-470): the forward returns the
-uint8 random values behind its decisions (`return_attn_probs=True`), the keep-mask derived from them
-(kept iff value <= floor(255 (1 - p)), :34-38) is handed to the oracle, and then
+Modelled on the reference's CUDA tests (tests/test_flash_attn.py:1007-1064, 1330-1380): `return_attn_probs=True` hands back
+S_dmask -- (b, h, seqlen_q rounded to 128, seqlen_k rounded to 128) in the input dtype, the probabilities relative to the
+running maximum of their key block with the dropout decision in the sign bit (csrc/flash_attn/src/dropout.h:26-33,
+flash_fwd_kernel.h:350-360).  It is decoded with the restatement of the reference's own decoder
+(oracle.convert_flash_attn_S_to_softmax / normalize_flash_attn_S, pinned to tests/test_flash_attn.py:411-526 by
+oracle/make_golden.py): the sign gives the keep-mask the oracle is run with, the magnitude must normalise to the oracle's
+attention probabilities, and then
     |out - out_ref|max <= 2 |out_pt - out_ref|max,   |dX - dX_ref|max <= 3 |dX_pt - dX_ref|max (+ atol)
-(the reference's ROCm backward bound is 10x; ours keeps the CUDA tests' 3x) and the measured drop fraction is within
-0.01 of p (tests/test_flash_attn.py:1046-1064 `dropout_fraction`).  Floating point; bounds are in _bound / the asserts.
+and the measured drop fraction is within 0.01 of the effective p of the 8-bit decision (keep iff hash byte <=
+floor(255 (1 - p))) (tests/test_flash_attn.py:1046-1064 `dropout_fraction`).  Floating point; bounds are in _bound / the asserts.
 """
 import math
 
@@ -57,11 +61,23 @@ def _run_case(dtype, b, sq, sk, h, hk, d, p_drop, causal, window=(-1, -1), alibi
     bias = oracle.attn_bias_from_alibi_slopes(slopes, sq, sk, causal=causal) if alibi else None
     ql, kl, vl = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
     torch.manual_seed(1234 + seed)
-    out, lse, randval = fa.flash_attn_func(ql, kl, vl, p_drop, causal=causal, window_size=window,
-                                           alibi_slopes=slopes.to(DEV) if alibi else None, return_attn_probs=True)
-    assert randval.dtype == torch.uint8 and tuple(randval.shape) == (b, h, sq, sk)
+    out, lse, S = fa.flash_attn_func(ql, kl, vl, p_drop, causal=causal, window_size=window,
+                                     alibi_slopes=slopes.to(DEV) if alibi else None, return_attn_probs=True)
+    r128 = lambda x: (x + 127) // 128 * 128
+    assert S.dtype == dtype and tuple(S.shape) == (b, h, r128(sq), r128(sk))  # csrc/flash_attn/flash_api.cpp:436-449
     dq, dk, dv = torch.autograd.grad(out, (ql, kl, vl), g.to(DEV))
-    keep = (randval <= math.floor(255.0 * (1 - p_drop))).cpu()
+    S_conv = oracle.convert_flash_attn_S_to_softmax(S.cpu(), sq, sk, None, None, causal=causal, window_size=window)
+    keep = S_conv >= 0                                   # tests/test_flash_attn.py:1021
+    # the magnitudes normalise to the attention probabilities (:1023-1036; bound :1125-1127 `attn`)
+    k_rep = k.repeat_interleave(h // hk, dim=2)
+    attn = oracle.normalize_flash_attn_S(S_conv.abs(), q, k_rep, k_rep, None, None, bias, True, causal=causal,
+                                         window_size=window)
+    _, attn_ref = oracle.attention_ref(q, k, v, None, None, attn_bias=bias, causal=causal, window_size=window)
+    _, attn_pt = oracle.attention_ref(q, k, v, None, None, attn_bias=bias, causal=causal, window_size=window, upcast=False,
+                                      reorder_ops=True)
+    aerr = (attn.float() - attn_ref.float()).abs().max().item()
+    abound = 2 * (attn_pt.float() - attn_ref.float()).abs().max().item() + 2e-3
+    assert aerr <= abound, f"attention probabilities decoded from S_dmask: {aerr:.3e} > {abound:.3e}"
 
     def run(**extra):
         q2, k2, v2 = (t.clone().requires_grad_(True) for t in (q, k, v))
@@ -76,7 +92,7 @@ def _run_case(dtype, b, sq, sk, h, hk, d, p_drop, causal, window=(-1, -1), alibi
         assert err <= _bound(r, p_, mult), f"{name}: {err:.3e} > {_bound(r, p_, mult):.3e}"
     vis = _visible(sq, sk, causal, window).expand(b, h, sq, sk)
     frac = ((~keep) & vis).sum().item() / max(1, vis.sum().item())
-    return frac, randval
+    return frac, S
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
@@ -114,10 +130,9 @@ def test_dropout_seed_semantics():
     o3, _, m3 = fa.flash_attn_func(q, k, v, 0.3, return_attn_probs=True)
     assert torch.equal(m1, m3) and torch.equal(o1, o3)
     assert not torch.equal(m1, m2)
-    assert not torch.equal(m1[0, 0], m1[0, 1]) and not torch.equal(m1[0, 0], m1[1, 0])
-    # the 8-bit values are uniform: mean ~127.5, every value occurs
-    assert abs(m1.float().mean().item() - 127.5) < 1.0
-    assert torch.bincount(m1.flatten().long(), minlength=256).min().item() > 0
+    k1 = m1 >= 0   # the decisions
+    assert not torch.equal(k1[0, 0], k1[0, 1]) and not torch.equal(k1[0, 0], k1[1, 0])
+    assert abs((~k1[:, :, :256, :256]).float().mean().item() - (1 - (math.floor(255 * 0.7) + 1) / 256)) < 0.01
     # without return_attn_probs the same seed gives the same output (the mask does not depend on recording it)
     torch.manual_seed(7)
     o4 = fa.flash_attn_func(q, k, v, 0.3)
@@ -128,8 +143,9 @@ def test_dropout_seed_semantics():
 
 @pytest.mark.parametrize("causal", [False, True])
 def test_dropout_varlen(causal):
-    """flash_attn_varlen_func under dropout: the random values come back as (h, total_q, max_seqlen_k)
-    (tests/test_flash_attn_ck.py:40-62); per sequence they give the keep-mask the oracle is run with."""
+    """flash_attn_varlen_func under dropout: S_dmask comes back as (b, h, max_seqlen_q rounded to 128, max_seqlen_k rounded to
+    128), sequence i's block at [i, :, :seqlen_q_i, :seqlen_k_i] (csrc/flash_attn/flash_api.cpp:648-660); its signs give the
+    keep-mask the oracle is run with."""
     fa = _api()
     gen = torch.Generator().manual_seed(11)
     b, h, hk, d, p_drop = 4, 4, 2, 64, 0.17
@@ -143,15 +159,20 @@ def test_dropout_varlen(causal):
     ck = torch.tensor([0] + list(torch.tensor(lens_k).cumsum(0)), dtype=torch.int32)
     ql, kl, vl = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
     torch.manual_seed(5)
-    out, lse, randval = fa.flash_attn_varlen_func(ql, kl, vl, cq.to(DEV), ck.to(DEV), msq, msk, p_drop, causal=causal,
-                                                  return_attn_probs=True)
-    assert randval.dtype == torch.uint8 and tuple(randval.shape) == (h, sum(lens_q), msk)
+    out, lse, S = fa.flash_attn_varlen_func(ql, kl, vl, cq.to(DEV), ck.to(DEV), msq, msk, p_drop, causal=causal,
+                                            return_attn_probs=True)
+    assert S.dtype == torch.bfloat16 and tuple(S.shape) == (b, h, (msq + 127) // 128 * 128, (msk + 127) // 128 * 128)
     dq, dk, dv = torch.autograd.grad(out, (ql, kl, vl), g.to(DEV))
-    keep_all = (randval <= math.floor(255.0 * (1 - p_drop))).cpu()
+    S = S.cpu()
     for i in range(b):
         sq_, sk_ = lens_q[i], lens_k[i]
         rq, rk = slice(cq[i], cq[i + 1]), slice(ck[i], ck[i + 1])
-        keep = keep_all[:, rq, :sk_].unsqueeze(0)
+        S_i = oracle.convert_flash_attn_S_to_softmax(S[i:i + 1], sq_, sk_, None, None, causal=causal)
+        keep = S_i >= 0
+        k_rep = k[rk][None].repeat_interleave(h // hk, dim=2)
+        attn = oracle.normalize_flash_attn_S(S_i.abs(), q[rq][None], k_rep, k_rep, None, None, None, True, causal=causal)
+        _, attn_ref = oracle.attention_ref(q[rq][None], k[rk][None], v[rk][None], None, None, causal=causal)
+        assert (attn.float() - attn_ref.float()).abs().max().item() <= 2e-2, f"seq {i}: decoded attention"
 
         def run(**extra):
             q2, k2, v2 = (t[None].clone().requires_grad_(True) for t in (q[rq], k[rk], v[rk]))
