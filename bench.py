@@ -146,6 +146,54 @@ def cpu_baseline(w, budget_s=20.0):
     }
 
 
+def check_rows(w, q, k, v, extra, result, n_rows=64):
+    """After the timed region (never inside it): 64 sampled rows of the tensor the last step produced, all heads, against
+    the oracle -- a kernel that exits early or computes something else must not print a number unnoticed.  Bound = the
+    tests' (|out - ref|max <= 2 |pt - ref|max + atol, tests/test_flash_attn.py:1121; fp8: hopper/test_flash_attn.py:193-194).
+    Checker only: imports oracle/, never the other way round.  Returns (ok, max error, bound)."""
+    import torch
+    from oracle import attention_ref as oracle
+    _, b, h, hk, s, d, causal, lens = w
+    out = (result[0] if isinstance(result, (tuple, list)) else result).float().cpu()
+    g = torch.Generator().manual_seed(1)
+    fp8 = "fp8" in extra
+    worst, worst_bound = 0.0, 0.0
+    seqs = [(i, 0, s) for i in range(b)] if lens is None else []
+    if lens is not None:
+        cu = extra["cu"].cpu().tolist()
+        seqs = [(i, cu[i], cu[i + 1] - cu[i]) for i in range(len(lens))]
+    per = max(1, n_rows // len(seqs))
+    for i, start, length in seqs:
+        rows = torch.randperm(length, generator=g)[:per].sort().values
+        if lens is None:
+            qi, ki, vi, oi = q[i, rows].cpu()[None], k[i].cpu()[None], v[i].cpu()[None], out[i, rows][None]
+        else:
+            sl = slice(start, start + length)
+            qi, ki, vi, oi = q[sl][rows].cpu()[None], k[sl].cpu()[None], v[sl].cpu()[None], out[sl][rows][None]
+        bias = None
+        if causal:  # the row subset's causal mask as an additive bias (tests/test_oracle.py pins this form)
+            jj = torch.arange(length).view(1, -1)
+            bias = torch.where(jj <= rows.view(-1, 1), 0.0, float("-inf")).view(1, 1, len(rows), length)
+        kw = dict(attn_bias=bias)
+        if fp8:
+            qi, ki, vi = qi.float(), ki.float(), vi.float()
+            ref = oracle.attention_ref(qi, ki, vi, **kw)[0]
+            pt = oracle.attention_ref(qi.to(torch.bfloat16), ki.to(torch.bfloat16), vi.to(torch.bfloat16), upcast=False,
+                                      reorder_ops=True, intermediate_dtype=torch.float8_e4m3fn, **kw)[0]
+            atol = 2 * (ref.float() + 0.3 - 0.3 - ref.float()).abs().max().item()
+        else:
+            ref = oracle.attention_ref(qi, ki, vi, **kw)[0]
+            pt = oracle.attention_ref(qi, ki, vi, upcast=False, reorder_ops=True, **kw)[0]
+            atol = 1e-5
+        err = (oi - ref.float()).abs().max().item()
+        bound = 2 * (pt.float() - ref.float()).abs().max().item() + atol
+        if not (err <= bound) or err - bound > worst - worst_bound:
+            worst, worst_bound = err, bound
+        if not (err <= bound):
+            return False, err, bound
+    return True, worst, worst_bound
+
+
 def dry_run(args, w, rank, world, dist, timing_group):
     """CPU rehearsal (tests/test_bench_harness.py): same rendezvous, barriers, max-over-ranks timing and JSON line as the
     real run; the step is a fixed host-side wait instead of the kernel (there is no CPU fallback of the product path)."""
@@ -214,6 +262,7 @@ def main():
                     help="strong: c5 only, global batch 32 split over the GPUs (BASELINE config 5)")
     ap.add_argument("--variant", type=int, default=0, help="kernel variant override (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-check", action="store_true", help="skip the post-run comparison of 64 sampled output rows with the oracle")
     ap.add_argument("--dry-run", action="store_true", help="CPU rehearsal of launch/rendezvous/reporting (gloo, no kernel)")
     args = ap.parse_args()
     if args.scaling == "strong" and args.workload != "c5":
@@ -326,9 +375,10 @@ def main():
     if dist is not None:
         dist.barrier(group=timing_group)
     t0 = time.perf_counter()
+    result = None
     for a, b_ in ev:
         a.record()
-        step()
+        result = step()
         b_.record()
     torch.cuda.synchronize()
     if dist is not None:
@@ -399,6 +449,18 @@ def main():
             out["cpu_baseline"] = cpu_baseline(w)
         else:
             out["cpu_baseline"] = None
+        # outside the timed region: 64 sampled rows of what the last step wrote, against the oracle
+        if args.workload in ("c2", "c3", "c4", "c5") and not args.no_check:
+            ok, err, bound = check_rows(w, q, k, v, extra, result)
+            out["checked"] = bool(ok)
+            out["check"] = {"rows": 64, "max_err": round(err, 6), "bound": round(bound, 6),
+                            "against": "oracle/attention_ref.py, all heads, bound 2 |pt - ref| + atol"}
+            if not ok:
+                print(json.dumps(out), flush=True)
+                print(f"bench.py: sampled output rows differ from the oracle (err {err:.3e} > bound {bound:.3e})", file=sys.stderr)
+                sys.exit(3)
+        else:
+            out["checked"] = None
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
