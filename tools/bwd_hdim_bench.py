@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
 """Backward timing per head dim (dq + dk + dv from dout; reference FLOP convention 2.5 x forward): s = 8192, b 2, h = 2048 / d."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import flash_attention_annotated_amd as fa
 

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Sliding-window forward timing (Mistral-style local attention): b2 h16 d128, window (W, 0) over s = 16384."""
 import sys
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import flash_attention_annotated_amd as fa
 
