@@ -179,7 +179,7 @@ HASH_PATH = os.path.join(_HERE, "libfa_fwd_gfx950.srchash")
 
 
 def _deps():
-    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))) + [
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".cpp"))) + [
         os.path.join(INCLUDE, "fa_fwd.h"), os.path.join(INCLUDE, "fa_bwd.h")]
 
 
@@ -196,7 +196,7 @@ def source_hash():
 def is_stale():
     """True when the built library is missing or was not built from the sources in the tree (content hash, not mtimes:
     the tree is copied to the GPU box)."""
-    if not os.path.exists(LIB_PATH) or not os.path.exists(HASH_PATH):
+    if not os.path.exists(LIB_PATH) or not os.path.exists(HASH_PATH) or not os.path.exists(binding_path()):
         return True
     return open(HASH_PATH).read().strip() != source_hash()
 
@@ -214,9 +214,35 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
+    build_binding(verbose)
     with open(HASH_PATH, "w") as f:
         f.write(source_hash() + "\n")
     return LIB_PATH
+
+
+def binding_path():
+    import sysconfig
+    return os.path.join(_HERE, "flash_attn_2_cuda_C" + sysconfig.get_config_var("EXT_SUFFIX"))
+
+
+def build_binding(verbose=False):
+    """The compiled `flash_attn_2_cuda` surface (csrc/torch_binding.cpp): host-only C++ over the C-ABI, plain g++ against
+    the torch headers (no hipify: there is no device code in it), linked to the library next to it."""
+    import sysconfig
+    import torch
+    tdir = os.path.dirname(torch.__file__)
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", os.path.join(CSRC, "torch_binding.cpp"),
+           "-DTORCH_EXTENSION_NAME=flash_attn_2_cuda_C", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}",
+           "-I", INCLUDE, "-I", os.path.join(tdir, "include"), "-I", os.path.join(tdir, "include", "torch", "csrc", "api", "include"),
+           "-I", "/opt/rocm/include", "-I", sysconfig.get_paths()["include"],
+           "-L", os.path.join(tdir, "lib"), "-ltorch", "-ltorch_cpu", "-lc10", "-lc10_hip", "-ltorch_hip", "-ltorch_python",
+           "-L", _HERE, f"-l:{LIB_NAME}", "-Wl,-rpath,$ORIGIN", f"-Wl,-rpath,{os.path.join(tdir, 'lib')}",
+           "-o", binding_path()]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    return binding_path()
 
 
 _lib = None

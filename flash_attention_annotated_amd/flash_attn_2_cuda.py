@@ -11,10 +11,16 @@ checks, output allocation, params — and enqueue the gfx950 kernel through the 
 
 `bwd` / `varlen_bwd` do the same for mha_bwd (:767-971) / mha_varlen_bwd (:973-1200) through include/fa_bwd.h.
 `fwd_kvcache` covers the decode path (mha_fwd_kvcache :1202-1476): in-place append, rotary, cache_batch_idx, paged
-and left-padded caches, split-KV.  Dropout / return_softmax are rejected by message.
+and left-padded caches, split-KV.
+
+Two bindings of the same host logic (round 3): the COMPILED module `flash_attn_2_cuda_C` (csrc/torch_binding.cpp: the pybind
+module of flash_api.cpp:1478-1485, host-only C++ against the torch headers, built by `_lib.build()` with plain g++) is what
+the five names resolve to when it is built; the Python statements below (ctypes onto the same C-ABI) are the fallback and
+what `FA_BINDING=python` selects.  Both enqueue the same kernels of libfa_fwd_gfx950.so.
 """
 import contextlib
 import math
+import os
 import threading
 from typing import List, Optional
 
@@ -624,3 +630,26 @@ def _fwd_kvcache_impl(q: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tenso
             out_.copy_(out)
             out = out_
     return [out, softmax_lse]
+
+
+# ---- the compiled binding takes over the five entry points when it is built (see the module docstring) -----------------
+_py_entry_points = {"fwd": fwd, "varlen_fwd": varlen_fwd, "bwd": bwd, "varlen_bwd": varlen_bwd, "fwd_kvcache": fwd_kvcache,
+                    "_fwd_kvcache_impl": _fwd_kvcache_impl, "fa3_window_rule": fa3_window_rule}
+compiled = None
+if os.environ.get("FA_BINDING", "compiled") != "python":
+    try:
+        from . import flash_attn_2_cuda_C as compiled  # noqa: F811
+    except ImportError:
+        compiled = None
+if compiled is not None:
+    fwd, varlen_fwd, bwd, varlen_bwd, fwd_kvcache = (compiled.fwd, compiled.varlen_fwd, compiled.bwd, compiled.varlen_bwd,
+                                                     compiled.fwd_kvcache)
+    _fwd_kvcache_impl = compiled._fwd_kvcache_impl
+
+    @contextlib.contextmanager
+    def fa3_window_rule():  # noqa: F811
+        prev = compiled._set_fa3_window_rule(True)
+        try:
+            yield
+        finally:
+            compiled._set_fa3_window_rule(prev)
