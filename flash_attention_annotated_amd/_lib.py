@@ -29,6 +29,7 @@ EXPORTED_SYMBOLS = (
     "fa_abi_version",
     "fa_fwd_tile_shape",
     "fa_set_default_variant",
+    "fa_set_persist_mode",
     "fa_kvcache_append",
     "fa_kvcache_append_params_size",
     "fa_rotary_apply",
@@ -275,6 +276,8 @@ def load():
     lib.fa_fwd_tile_shape.restype = ctypes.c_int
     lib.fa_set_default_variant.argtypes = [ctypes.c_int32]
     lib.fa_set_default_variant.restype = None
+    lib.fa_set_persist_mode.argtypes = [ctypes.c_int32]
+    lib.fa_set_persist_mode.restype = None
     lib.fa_kvcache_append.argtypes = [ctypes.POINTER(FaKvcacheAppendParams), ctypes.c_void_p]
     lib.fa_kvcache_append.restype = ctypes.c_int
     lib.fa_kvcache_append_params_size.argtypes = []
@@ -307,6 +310,8 @@ def load():
         raise RuntimeError("fa_fwd ABI version mismatch")
     if os.environ.get("FA_FWD_VARIANT"):  # developer override of the kernel shape (never changes results)
         lib.fa_set_default_variant(int(os.environ["FA_FWD_VARIANT"]))
+    if os.environ.get("FA_FWD_PERSIST"):  # developer override: -1 never / 1 always the persistent 256-row kernel (never changes results)
+        lib.fa_set_persist_mode(int(os.environ["FA_FWD_PERSIST"]))
     _lib = lib
     return lib
 

@@ -16,6 +16,7 @@
 namespace {
 
 std::atomic<int> g_default_variant{0};
+std::atomic<int> g_persist_mode{0};  // test hook: 0 = the library's choice, -1 = never the persistent kernel, 1 = whenever it can run
 
 // ---- fp8 e4m3 -> bf16 expansion (exact), strided source -> contiguous (rows, heads, d) destination ------------------
 // One thread = 8 elements (8-byte load, 16-byte store).  HBM-bound elementwise pass.
@@ -504,10 +505,10 @@ int launch(const fa::KParams &kp, hipStream_t stream) {
     return FA_OK;
 }
 
-template <typename T, int D, bool SOFTCAP, int DEFF = D>
+template <typename T, int D, bool SOFTCAP, int DEFF = D, bool PERSIST = false>
 int launch_w64(const fa::KParams &kp, hipStream_t stream) {
     constexpr int smem = fa::smem_bytes_w64<D>();
-    auto kernel = fa::fwd_kernel_w64<T, D, SOFTCAP, DEFF>;
+    auto kernel = fa::fwd_kernel_w64<T, D, SOFTCAP, DEFF, PERSIST>;
     // the > 64 KiB dynamic-LDS opt-in is a per-device attribute of the kernel: one bit per device ordinal
     static std::atomic<uint64_t> attr_set{0};
     int dev = 0;
@@ -520,9 +521,33 @@ int launch_w64(const fa::KParams &kp, hipStream_t stream) {
         }
         attr_set.fetch_or(bit, std::memory_order_release);
     }
-    hipLaunchKernelGGL(kernel, dim3(kp.grid * (kp.num_splits > 1 ? kp.num_splits : 1)), dim3(256), smem, stream, kp);
+    // PERSIST: one workgroup per CU (a multiple of 8: ids go round-robin over the XCDs), each walks its chain of the slot list
+    const int wgs = PERSIST ? std::min(kp.grid, kp.num_cus & ~7) : kp.grid * (kp.num_splits > 1 ? kp.num_splits : 1);
+    hipLaunchKernelGGL(kernel, dim3(wgs), dim3(256), smem, stream, kp);
     if (hipGetLastError() != hipSuccess) return FA_ERR_LAUNCH;
     return FA_OK;
+}
+
+// The persistent form of the 256-row kernel (fa_fwd_kernel_w64.h, PERSIST): plain dense problems at head dims 97..128 whose
+// every work item sweeps at least three 64-key tiles and whose K / V tensors one 32-bit raw buffer descriptor can span.
+bool persist_ok(const fa::KParams &kp) {
+    const int mode = g_persist_mode.load();
+    if (mode < 0) return false;
+    if (kp.cu_seqlens_q || kp.cu_seqlens_k || kp.seqused_q || kp.seqused_k || kp.leftpad_k || kp.kv_batch_idx || kp.block_table) return false;
+    if (kp.alibi || kp.q_descale || kp.k_descale || kp.v_descale || kp.num_splits > 1 || kp.rp_dropout != 1.f) return false;
+    if (kp.d <= 96 || kp.d > 128 || kp.window_left >= 0) return false;
+    if (kp.seqlen_k % 64 != 0 || kp.seqlen_k < 192 || kp.seqlen_q > kp.seqlen_k) return false;  // (causal: bottom-right aligned, shift >= 0)
+    if ((kp.num_cus & ~7) < 8) return false;
+    auto extent = [&](int64_t bs, int64_t hs, int64_t rs, int lead) {
+        return ((int64_t)(kp.b - 1) * bs + (int64_t)(kp.h_k - 1) * hs + (int64_t)(kp.seqlen_k - 1 + lead) * rs + 128) * 2;
+    };
+    if (kp.k_batch_stride < 0 || kp.k_head_stride < 0 || kp.k_row_stride <= 0 || kp.v_batch_stride < 0 || kp.v_head_stride < 0 || kp.v_row_stride <= 0) return false;
+    if (extent(kp.k_batch_stride, kp.k_head_stride, kp.k_row_stride, 32) >= (1ll << 32) - 65536 ||
+        extent(kp.v_batch_stride, kp.v_head_stride, kp.v_row_stride, 0) >= (1ll << 32) - 65536) return false;
+    if ((int64_t)kp.seqlen_k * kp.k_row_stride >= (1ll << 30) || (int64_t)kp.seqlen_k * kp.v_row_stride >= (1ll << 30)) return false;
+    // (mode 0: off for now -- correct and bit-identical, but an item switch still costs more than a workgroup hand-over:
+    //  profiles/r3_persist.txt; fa_set_persist_mode(1) turns it on for every problem it can run)
+    return mode > 0;
 }
 
 // head dims 129 .. 256, plain features: 4 waves x 32 rows around the generated loop FastLoop256 (fa_fwd_kernel_d256.h)
@@ -573,8 +598,10 @@ int dispatch_variant(const fa::KParams &kp, bool softcap, int variant, hipStream
     } else {
         if (variant == 0 || variant == 3) {
             if (softcap) return launch_w64<T, D, true>(kp, stream);
-            if constexpr (D == 128)
+            if constexpr (D == 128) {
                 if (kp.d <= 96) return launch_w64<T, D, false, 96>(kp, stream);  // head-dim tile 96 (hopper/tile_size.h:10-54)
+                if (persist_ok(kp)) return launch_w64<T, D, false, 128, true>(kp, stream);
+            }
             return launch_w64<T, D, false>(kp, stream);
         }
         if (variant == 2) {
@@ -628,6 +655,7 @@ int fa_debug_read_cycles(unsigned long long *dst) {
 }
 #endif
 void fa_set_default_variant(int32_t variant) { g_default_variant.store(variant); }
+void fa_set_persist_mode(int32_t mode) { g_persist_mode.store(mode); }
 
 const char *fa_strerror(int status) {
     switch (status) {

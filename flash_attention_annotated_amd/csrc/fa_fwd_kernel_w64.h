@@ -369,24 +369,48 @@ __device__ unsigned long long fa_timing_buf[32 * 4096];
 #ifndef FA_CYCLES_WG0
 #define FA_CYCLES_WG0 0   // first of the 256 workgroups whose stamps are kept (0: the launch's first round, cold caches)
 #endif
+#ifndef FA_CYCLES_STRIDE
+#define FA_CYCLES_STRIDE 1  // keep every n-th workgroup id of the window (2: two launch rounds of the even XCDs -> CU hand-over gaps)
+#endif
 __device__ unsigned long long fa_cycle_buf[256 * 4 * 64];
-#define FA_C() do { if (cyc_n < 60) { unsigned long long *cb_ = (unsigned long long *)(smem + 6 * BLOCK_N * D * 2 + 1024) + (threadIdx.x >> 6) * 64; \
+#define FA_C() do { if (!PERSIST && cyc_n < 60) { unsigned long long *cb_ = (unsigned long long *)(smem + 6 * BLOCK_N * D * 2 + 1024) + (threadIdx.x >> 6) * 64; \
         if (cyc_n == 0) cb_[62] = __builtin_amdgcn_s_memrealtime(); cb_[cyc_n++] = __builtin_amdgcn_s_memtime(); cb_[63] = __builtin_amdgcn_s_memrealtime(); cb_[61] = cyc_n; } } while (0)
-#define FA_STAMP(k) (((unsigned long long *)(smem + 6 * BLOCK_N * D * 2 + 1024))[(threadIdx.x >> 6) * 64 + (k)] = __builtin_amdgcn_s_memrealtime())
+// (PERSIST keeps the next item's Q in that image during the sweep: its stamps go to fa_cycle_buf directly, FA_PSTAMP below)
+#define FA_STAMP(k) do { if constexpr (!PERSIST) ((unsigned long long *)(smem + 6 * BLOCK_N * D * 2 + 1024))[(threadIdx.x >> 6) * 64 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+                         else FA_PSTAMP(k); } while (0)
 // (the stamp area lies inside the Q staging image: stamps taken before the Q fragments are in registers wait in scalars)
 #define FA_STAMP_VAR(k) const unsigned long long fa_st_##k = __builtin_amdgcn_s_memrealtime()
-#define FA_STAMP_FLUSH(k) (((unsigned long long *)(smem + 6 * BLOCK_N * D * 2 + 1024))[(threadIdx.x >> 6) * 64 + (k)] = fa_st_##k)
+#define FA_STAMP_FLUSH(k) do { if constexpr (!PERSIST) ((unsigned long long *)(smem + 6 * BLOCK_N * D * 2 + 1024))[(threadIdx.x >> 6) * 64 + (k)] = fa_st_##k; } while (0)
+// persistent kernel: the workgroup's item number `fa_item` (0, 1, ...) selects the row: stamps of items 1 and 2 are kept
+#define FA_PSTAMP(k) do { if (fa_item >= 1 && fa_item <= 2 && blockIdx.x < 128) \
+    fa_cycle_buf[((blockIdx.x * 2 + fa_item - 1) * 4 + (threadIdx.x >> 6)) * 64 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define FA_STAMP_ENTRY() const unsigned long long fa_st_entry = __builtin_amdgcn_s_memrealtime()
+#define FA_STAMP_ENTRY_FLUSH(k) do { if constexpr (!PERSIST) ((unsigned long long *)(smem + 6 * BLOCK_N * D * 2 + 1024))[(threadIdx.x >> 6) * 64 + (k)] = fa_st_entry; } while (0)
+// XCC_ID (hwreg 20) << 32 | HW_ID (hwreg 4: cu_id [11:8], sh_id [12], se_id [15:13]): which CU ran this workgroup
+#define FA_STAMP_HWID(k) do { if constexpr (D == 128 && !PERSIST) ((unsigned long long *)(smem + 6 * BLOCK_N * D * 2 + 1024))[(threadIdx.x >> 6) * 64 + (k)] = \
+    ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32) | __builtin_amdgcn_s_getreg(4 | (31 << 11)); } while (0)
 #else
 #define FA_C()
 #define FA_STAMP(k)
 #define FA_STAMP_VAR(k)
 #define FA_STAMP_FLUSH(k)
+#define FA_PSTAMP(k)
+#define FA_STAMP_HWID(k)
+#define FA_STAMP_ENTRY()
+#define FA_STAMP_ENTRY_FLUSH(k)
 #endif
 
 // DEFF (head-dim tile 128 only): 96 when the head dim is <= 96 -- the generated loop then skips the k-steps and O blocks
 // of the zero padding (6 + 6 instead of 8 + 8 MFMA pairs per half-step; the LDS images keep their 256-byte rows).
-template <typename T, int D, bool SOFTCAP, int DEFF = D>
+//
+// PERSIST (head-dim tile 128, dense batches, plain features: the host decides, fa_fwd_api.hip persist_ok()): one workgroup per
+// CU walks a chain of work items (role of hopper/tile_scheduler.hpp:140-214 + flash_fwd_kernel_sm90.h:308-359).  The K / V
+// look-ahead stream of an item's last three tiles fetches the NEXT item's first tiles instead of rows past the end, its Q
+// lands in the Q staging image (dead once the fragments are in registers) during the sweep, and the epilogue stages O in
+// that image -- so an item switch costs the epilogue and the first scores, not the loads in front of them.
+template <typename T, int D, bool SOFTCAP, int DEFF = D, bool PERSIST = false>
 __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
+    static_assert(!PERSIST || (D == 128 && DEFF == 128 && !SOFTCAP), "the persistent form exists for the plain head-dim-128 kernel");
     constexpr int NT = 256;
     constexpr int BLOCK_M = 256;
     constexpr int KSTEPS = D / 16;
@@ -407,10 +431,11 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     const int r = lane & 31;
     const int hh = lane >> 5;
 
+    FA_STAMP_ENTRY();  // kernel entry (developer builds)
     int m_block, head, batch;
     int split;
     if (!decode_tile(p, m_block, head, batch, split)) return;  // whole workgroup (padding)
-    const int kv_head = head / p.h_ratio;
+    int kv_head = head / p.h_ratio;
 
     int sq, sk;
     int64_t q_base, k_base, v_base, o_base, lse_base;
@@ -437,7 +462,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
         k_base = (int64_t)kv_batch * p.k_batch_stride;
         v_base = (int64_t)kv_batch * p.v_batch_stride;
     }
-    const int row_lo = m_block * BLOCK_M;
+    int row_lo = m_block * BLOCK_M;
     if (row_lo >= sq) return;
     FA_T(0);
 
@@ -449,10 +474,47 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
         k_base += (int64_t)lp * p.k_row_stride;
         v_base += (int64_t)lp * p.v_row_stride;
     }
+#ifdef FA_CYCLES
+    // (the entry stamp counts as a memory write in front of the cu_seqlens / leftpad lookups, which hipcc then issues as vector
+    //  loads: "s" asm operands derived from them no longer assemble -- make them scalars again; developer builds only)
+    auto uni64 = [](int64_t x) {
+        return (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(x >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)x));
+    };
+    sq = __builtin_amdgcn_readfirstlane(sq); sk = __builtin_amdgcn_readfirstlane(sk);
+    q_base = uni64(q_base); k_base = uni64(k_base); v_base = uni64(v_base); o_base = uni64(o_base); lse_base = uni64(lse_base);
+#endif
     const T *qp = (const T *)p.q + q_base + (int64_t)head * p.q_head_stride;
     const T *kp = (const T *)p.k + k_base + (int64_t)kv_head * p.k_head_stride;
     const T *vp = (const T *)p.v + v_base + (int64_t)kv_head * p.v_head_stride;
     T *op = (T *)p.o + o_base + (int64_t)head * p.o_head_stride;
+    // PERSIST: the chain of this workgroup.  Round t of the CU with index k inside its XCD (blockIdx.x >> 3; the launch is one
+    // workgroup per CU, ids dealt round-robin over the XCDs) takes slot cpx t + k of the XCD's slot list (tile_of_wg), odd
+    // rounds in reverse (cpx - 1 - k): under a causal mask the slots of a unit get lighter in order, and the zig-zag pairs a
+    // heavy item with a light one.  Placement is a speed matter only: every item is taken by exactly one workgroup.
+    int chain_round = 0;
+    bool has_next = false;
+    int m_block_n = 0, head_n = 0, batch_n = 0;
+    const T *kp_n = kp, *vp_n = vp;
+    auto chain_next = [&]() {  // (m_block_n, head_n, batch_n) of the next valid item of the chain, or has_next = false
+        const int cpx = (int)gridDim.x >> 3, k = (int)blockIdx.x >> 3, xcd = (int)blockIdx.x & 7;
+        has_next = false;
+        for (int t = chain_round + 1;; ++t) {
+            const int slot = cpx * t + ((t & 1) ? cpx - 1 - k : k);
+            if (cpx * t * 8 >= p.grid) break;           // the whole round lies behind the slot list
+            const int wg = slot * 8 + xcd;
+            if (wg >= p.grid) continue;
+            const int tile = tile_of_wg(p, wg);
+            if (tile >= p.num_tiles) continue;
+            const int per_kvh = p.h_ratio * p.num_m_blocks;
+            const int bk = tile / per_kvh, r2 = tile % per_kvh;
+            batch_n = __builtin_amdgcn_readfirstlane(bk / p.h_k);
+            m_block_n = __builtin_amdgcn_readfirstlane(p.num_m_blocks - 1 - r2 / p.h_ratio);
+            head_n = __builtin_amdgcn_readfirstlane((bk % p.h_k) * p.h_ratio + r2 % p.h_ratio);
+            chain_round = t;
+            has_next = true;
+            break;
+        }
+    };
 
     // The few kernel arguments the main loop needs, detached from the kernarg SGPR tuples (hipcc loads the by-value
     // struct as s_load_dwordx8/x16 tuples and, once those spill, reloads a whole tuple through v_readlane -- VALU
@@ -470,26 +532,30 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     asm volatile("" : "+s"(scale_e), "+s"(vdesc_e));
 
     const int shift = sk - sq;
-    const int row_hi = min(sq, row_lo + BLOCK_M);
-    int key_hi = sk, key_lo = 0;
-    if (p.window_right >= 0) key_hi = min(sk, row_hi + shift + p.window_right);
-    if (p.window_left >= 0) key_lo = max(0, row_lo + shift - p.window_left);
-    int n_min_ = key_lo / BLOCK_N;
-    int n_max_ = key_hi > 0 ? (key_hi + BLOCK_N - 1) / BLOCK_N : 0;
-    split_range(p, split, n_min_, n_max_);
-    const int n_min = n_min_, n_max = n_max_;
-
-    const int wrow = row_lo + wave * 64;  // first row of this wave; q-block A = wrow.., B = wrow+32..
-    const int row_a = wrow + r, row_b = wrow + 32 + r;
-    // half-steps [0, jend) this wave computes (half-step j = keys [64 n_min + 32 j, +32)); later ones are
-    // fully masked for all of its 64 rows (causal / right window).  Waves past the end of q: none.
-    int jend = 2 * (n_max - n_min);
-    if (p.window_right >= 0) {
-        const int last_key = min(sk - 1, wrow + 63 + shift + p.window_right);
-        jend = min(jend, last_key >= n_min * BLOCK_N ? (last_key - n_min * BLOCK_N) / 32 + 1 : 0);
-    }
-    if (wrow >= sq || n_min >= n_max) jend = 0;
-    jend = __builtin_amdgcn_readfirstlane(jend);
+    int n_min, n_max, wrow, jend;
+    // key-tile range, first row and half-step count of this wave for the item in (row_lo, ...); PERSIST: again per item
+    auto item_geometry = [&]() {
+        const int row_hi = min(sq, row_lo + BLOCK_M);
+        int key_hi = sk, key_lo = 0;
+        if (p.window_right >= 0) key_hi = min(sk, row_hi + shift + p.window_right);
+        if (p.window_left >= 0) key_lo = max(0, row_lo + shift - p.window_left);
+        int n_min_ = key_lo / BLOCK_N;
+        int n_max_ = key_hi > 0 ? (key_hi + BLOCK_N - 1) / BLOCK_N : 0;
+        split_range(p, split, n_min_, n_max_);
+        n_min = __builtin_amdgcn_readfirstlane(n_min_);
+        n_max = __builtin_amdgcn_readfirstlane(n_max_);
+        wrow = __builtin_amdgcn_readfirstlane(row_lo + wave * 64);  // first row of this wave; q-block A = wrow.., B = wrow+32..
+        // half-steps [0, jend) this wave computes (half-step j = keys [64 n_min + 32 j, +32)); later ones are
+        // fully masked for all of its 64 rows (causal / right window).  Waves past the end of q: none.
+        jend = 2 * (n_max - n_min);
+        if (p.window_right >= 0) {
+            const int last_key = min(sk - 1, wrow + 63 + shift + p.window_right);
+            jend = min(jend, last_key >= n_min * BLOCK_N ? (last_key - n_min * BLOCK_N) / 32 + 1 : 0);
+        }
+        if (wrow >= sq || n_min >= n_max) jend = 0;
+        jend = __builtin_amdgcn_readfirstlane(jend);
+    };
+    item_geometry();
 
     FA_STAMP_VAR(46);
     // ---- Q fragments (B operand of S^T = K.Q^T): fetched in the prologue below, behind the first K tile ----------
@@ -521,9 +587,13 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     int ld_row[LD_PER_THREAD], ld_col[LD_PER_THREAD];
     uint32_t koff[LD_PER_THREAD], voff[LD_PER_THREAD];  // byte offsets of this lane's chunks inside an in-range tile
     const int k_rs = (int)k_rs64, v_rs = (int)v_rs64;
+    int kbase, vbase;  // lane parts of the LDS fragment addresses (below)
+    // PERSIST: every per-lane table is rebuilt at the top of each work item from an opaque copy of the lane id -- kept alive
+    // across the item loop (through every asm block and the epilogue) they cost spills; rebuilt they cost ~40 VALU per item
+    auto lane_tables = [&](int lane_) {
 #pragma unroll
     for (int i = 0; i < LD_PER_THREAD; ++i) {
-        const int slot = wave * (LD_PER_THREAD * 64) + i * 64 + lane;  // 16-byte slot index inside the tile image
+        const int slot = wave * (LD_PER_THREAD * 64) + i * 64 + lane_;  // 16-byte slot index inside the tile image
         const int row = slot / CH_PER_ROW;
         // inverse of lds_off<D>: the chunk stored at slot position (slot % CH_PER_ROW) of this row
         int ch;
@@ -534,12 +604,28 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
         koff[i] = (uint32_t)(row * k_rs + ld_col[i]) * 2u;
         voff[i] = (uint32_t)(row * v_rs + ld_col[i]) * 2u;
     }
+    // ---- lane parts of the LDS read addresses; everything else is an immediate or one XOR ---------------
+    const int r_ = lane_ & 31, hh_ = lane_ >> 5, i16 = lane_ & 15, g1 = (lane_ >> 4) & 1;
+    kbase = lds_off<D>(r_, hh_);                                                          // ^ 32*ks, + half/buffer
+    vbase = lds_off<D>(4 * hh_ + (i16 >> 2), 2 * g1 + ((i16 >> 1) & 1)) + 8 * (i16 & 1);  // ^ (64 db + 32 j2)
+    };
+    lane_tables(lane);
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
     const uint32_t lds_wave = lds0 + wave * (LD_PER_THREAD * 1024);
     // Tile starting at key k0 (may start before 0 or reach past sk): rows clamped into [0, sk).  The wave-uniform
     // 64-bit base points at the first clamped row; lane offsets are 32-bit and never negative.
     auto dma_tile = [&](const T *seq, int row_stride, int64_t row_stride64, const uint32_t (&fast_off)[LD_PER_THREAD],
                         int k0, uint32_t lds) {
+        if constexpr (PERSIST) {
+            // seqlen_k is a multiple of 64 here and a wave fetches 16 whole rows of a tile (rows 16 wave ..): instead of
+            // clamping lanes, the wave's row group is moved into the sequence as a whole -- the rows this replaces (keys in
+            // front of a head's first or behind its last) are never multiplied with anything that is kept, they only have
+            // to be finite -- and the precomputed in-tile lane offsets serve every tile (no per-lane row / column tables
+            // alive across the item loop)
+            const int start = min(max(k0 + 16 * wave, 0), sk - 16) - 16 * wave;
+            lds_dma<LD_PER_THREAD>(lds, seq + (int64_t)start * row_stride64, fast_off);
+            return;
+        }
         const int base_row = min(max(k0, 0), sk - 1);
         const T *base = seq + (int64_t)base_row * row_stride64;
         if (k0 >= 0 && k0 + BLOCK_N <= sk) {  // whole tile in range (wave-uniform): precomputed lane offsets
@@ -555,13 +641,21 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
         }
     };
     // K tile m = keys [64m - 32, 64m + 32)
-    auto load_k = [&](int m, int buf) { dma_tile(kp, k_rs, k_rs64, koff, m * BLOCK_N - 32, lds_wave + buf * TILE_BYTES); };
-    auto load_v = [&](int n, int buf) { dma_tile(vp, v_rs, v_rs64, voff, n * BLOCK_N, lds_wave + (3 + buf) * TILE_BYTES); };
+    // PERSIST: tiles behind the item's last one are the NEXT item's first ones (n_min = 0 there).  K tile n_max is a hybrid:
+    // rows 0..31 = this item's last 32 keys (waves 0 and 1 fetch them), rows 32..63 = the next item's keys 0..31 (waves 2, 3).
+    auto load_k = [&](int m, int buf) {
+        if (PERSIST && has_next && (m > n_max || (m == n_max && wave >= 2)))
+            dma_tile(kp_n, k_rs, k_rs64, koff, (m - n_max) * BLOCK_N - 32, lds_wave + buf * TILE_BYTES);
+        else
+            dma_tile(kp, k_rs, k_rs64, koff, m * BLOCK_N - 32, lds_wave + buf * TILE_BYTES);
+    };
+    auto load_v = [&](int n, int buf) {
+        if (PERSIST && has_next && n >= n_max)
+            dma_tile(vp_n, v_rs, v_rs64, voff, (n - n_max) * BLOCK_N, lds_wave + (3 + buf) * TILE_BYTES);
+        else
+            dma_tile(vp, v_rs, v_rs64, voff, n * BLOCK_N, lds_wave + (3 + buf) * TILE_BYTES);
+    };
 
-    // ---- lane parts of the LDS read addresses; everything else is an immediate or one XOR ---------------
-    const int i16 = lane & 15, g1 = (lane >> 4) & 1;
-    const int kbase = lds_off<D>(r, hh);                                            // ^ 32*ks, + half/buffer
-    const int vbase = lds_off<D>(4 * hh + (i16 >> 2), 2 * g1 + ((i16 >> 1) & 1)) + 8 * (i16 & 1);  // ^ (64 db + 32 j2)
 
     // S(half kh of the K tile in buffer kbuf) for both q-blocks; every K fragment feeds two MFMAs
     auto qk_half = [&](int kbuf, int kh, f32x16 &sa, f32x16 &sb) {
@@ -728,9 +822,9 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     // rows past the end of q and head-dim chunks past d land as zeros.  (Round 1 gathered the fragments lane-per-row from
     // global memory, 32 B of each 128-B line per instruction: 2.4 us until the requests were even issued.)
     if (n_min < n_max) load_k(n_min, 0);
-    {
-        const int rows_here = min(sq - wrow, 64);  // <= 0: nothing of this wave's rows exists
-        const uint64_t qb_ = (uint64_t)(uintptr_t)(qp + (int64_t)wrow * p.q_row_stride);
+    auto q_dma = [&](const T *qhead, int wrow_) {  // rows [wrow_, wrow_ + 64) of the head at qhead -> this wave's Q image
+        const int rows_here = min(sq - wrow_, 64);  // <= 0: nothing of this wave's rows exists
+        const uint64_t qb_ = (uint64_t)(uintptr_t)(qhead + (int64_t)wrow_ * p.q_row_stride);
         u32x4 qdesc;
         qdesc[0] = (uint32_t)qb_;
         qdesc[1] = (uint32_t)(qb_ >> 32) & 0xffffu;  // stride 0: raw buffer
@@ -740,9 +834,16 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
         for (int i = 0; i < 4; ++i) qdesc[i] = __builtin_amdgcn_readfirstlane(qdesc[i]);
         const uint32_t q_img = lds0 + 6 * TILE_BYTES + wave * TILE_BYTES;
         const int q_rs = (int)p.q_row_stride;
+        // (PERSIST: the lane offsets are rebuilt per item from an opaque copy of the lane id -- hoisted out of the item loop
+        //  they are 16 registers that live across the whole sweep, i.e. spills with a vmcnt(0) wait in front of every reload)
+        int lane_q = lane;
+        if constexpr (PERSIST) {
+            lane_q = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            asm volatile("" : "+v"(lane_q));
+        }
 #pragma unroll
         for (int i = 0; i < CH_PER_ROW; ++i) {
-            const int slot = i * 64 + lane;
+            const int slot = i * 64 + lane_q;
             const int row = slot / CH_PER_ROW;
             int ch;  // inverse of lds_off<D>
             if constexpr (D == 64) ch = (slot % CH_PER_ROW) ^ ((((row >> 1) & 1) << 2) | ((row >> 2) & 3));
@@ -750,7 +851,8 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
             const uint32_t off = ch * 8 < p.d ? (uint32_t)(row * q_rs + ch * 8) * 2u : 0x7ffffff0u;
             lds_dma_buf1(q_img + i * 1024, qdesc, off);
         }
-    }
+    };
+    q_dma(qp, wrow);
     if (n_min < n_max) {
         load_v(n_min, 0);
         load_k(n_min + 1, 1);
@@ -763,22 +865,147 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     FA_STAMP_VAR(49);
     tile_barrier<0>();                   // first tiles landed (asm LDS-DMA) and visible to every wave
     FA_STAMP_VAR(50);
-    {
+    auto q_fragments = [&]() {
         const char *qimg = smem + 6 * TILE_BYTES + wave * TILE_BYTES;
+        int kb_ = kbase;
+        if constexpr (PERSIST) asm volatile("" : "+v"(kb_));  // (the 8 addresses are rebuilt per item, not kept alive across the sweep)
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
-            qa[ks] = *(const u32x4 *)(qimg + (kbase ^ (32 * ks)));
-            qb[ks] = *(const u32x4 *)(qimg + (kbase ^ (32 * ks)) + 32 * ROWB);
+            qa[ks] = *(const u32x4 *)(qimg + (kb_ ^ (32 * ks)));
+            qb[ks] = *(const u32x4 *)(qimg + (kb_ ^ (32 * ks)) + 32 * ROWB);
         }
-    }
-    // Q is only ever an MFMA operand: pin it into the AGPR half of the register file (born there, stays there)
+        // Q is only ever an MFMA operand: pin it into the AGPR half of the register file (born there, stays there)
 #pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) {
-        asm volatile("; pin Q" : "+a"(qa[ks]));
-        asm volatile("; pin Q" : "+a"(qb[ks]));
-    }
-    FA_STAMP_FLUSH(46); FA_STAMP_FLUSH(48); FA_STAMP_FLUSH(49); FA_STAMP_FLUSH(50);
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            asm volatile("; pin Q" : "+a"(qa[ks]));
+            asm volatile("; pin Q" : "+a"(qb[ks]));
+        }
+    };
+    if constexpr (!PERSIST) q_fragments();
+    FA_STAMP_FLUSH(46); FA_STAMP_FLUSH(48); FA_STAMP_FLUSH(49); FA_STAMP_FLUSH(50); FA_STAMP_ENTRY_FLUSH(53);
+    FA_STAMP_HWID(54);
     FA_T(2);
+    // ring phase: K / V tile i of the current item lives in ring slot (i + ph) % 3 (PERSIST: the rings run on across items)
+    int ph = 0;
+#ifdef FA_CYCLES
+    int fa_item = 0;
+#endif
+    // PERSIST: at an item switch the rings hold the next item's first tiles and the Q image its Q -- what is free is the V
+    // ring slot the next sweep's first tile fills (V tile 2 of the next item), and of that slot each wave owns the 4 KiB its
+    // own LDS-DMA pieces go to.  O is staged there in four passes of 16 rows (q-block A rows 0..15, 16..31, then B): unpadded
+    // 256-byte rows, 16-byte chunk c of row r at chunk slot c ^ r.  Wave-private and in order: no barrier, and the wave's
+    // next LDS-DMA into the region is issued after its last read of it has returned.
+    auto epilogue_persist = [&](int vslot) {
+        if constexpr (PERSIST) {
+        int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        asm volatile("" : "+v"(lane_e));  // (not hoisted out of the item loop: see lane_tables)
+        const int r_e = lane_e & 31, hh_e = lane_e >> 5;
+        const int row_a_e = wrow + r_e, row_b_e = wrow + 32 + r_e;
+        const float lt_a = half_swap_sum(l_a), lt_b = half_swap_sum(l_b);
+        const bool e_a = (lt_a == 0.f) || (lt_a != lt_a), e_b = (lt_b == 0.f) || (lt_b != lt_b);
+        const float inv_a = (e_a ? 1.f : 1.f / lt_a) * vdesc_e, inv_b = (e_b ? 1.f : 1.f / lt_b) * vdesc_e;
+        if (wrow >= sq) return;
+        if (hh_e == 0) {
+            if (row_a_e < sq) p.lse[lse_base + row_a_e] = e_a ? INFINITY : m_a * scale_e + __logf(lt_a);
+            if (row_b_e < sq) p.lse[lse_base + row_b_e] = e_b ? INFINITY : m_b * scale_e + __logf(lt_b);
+        }
+        char *obuf = smem + (3 + vslot) * TILE_BYTES + wave * (LD_PER_THREAD * 1024);
+        const int wr_off = (r_e & 15) * ROWB + 8 * hh_e;  // this lane's row inside a pass
+        const int rd_row = lane_e >> 4, rd_ch = lane_e & 15;  // read-back: lane -> (row rd_row + 4 i, chunk rd_ch)
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            if ((r_e >> 4) == (pass & 1)) {
+#pragma unroll
+                for (int db = 0; db < DBLOCKS; ++db)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        u32x2 w;
+                        if (pass < 2) {
+                            w[0] = Elem<T>::pack2(oa[db][4 * g4] * inv_a, oa[db][4 * g4 + 1] * inv_a);
+                            w[1] = Elem<T>::pack2(oa[db][4 * g4 + 2] * inv_a, oa[db][4 * g4 + 3] * inv_a);
+                        } else {
+                            w[0] = Elem<T>::pack2(ob[db][4 * g4] * inv_b, ob[db][4 * g4 + 1] * inv_b);
+                            w[1] = Elem<T>::pack2(ob[db][4 * g4 + 2] * inv_b, ob[db][4 * g4 + 3] * inv_b);
+                        }
+                        *(u32x2 *)(obuf + wr_off + (((db * 4 + g4) ^ (r_e & 15)) * 16)) = w;
+                    }
+            }
+            // (compiler barrier: the 8-byte stores and the 16-byte loads are different vector types, which type-based alias
+            //  analysis lets hipcc reorder -- rows then came back with the previous pass's content; the hardware keeps a wave's
+            //  LDS operations in order)
+            asm volatile("" ::: "memory");
+            u32x4 val[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = rd_row + 4 * i;
+                val[i] = *(const u32x4 *)(obuf + row * ROWB + ((rd_ch ^ row) * 16));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = wrow + 16 * pass + rd_row + 4 * i;
+                if (row < sq && rd_ch * 8 < p.d) *(u32x4 *)(op + (int64_t)row * p.o_row_stride + rd_ch * 8) = val[i];
+            }
+            asm volatile("" ::: "memory");  // (the next pass's stores stay behind this pass's loads)
+        }
+        }
+    };
+    bool first_item = true;
+    for (int it_ = 0; PERSIST || it_ < 1; ++it_) {  // work items of this workgroup (exactly one unless PERSIST)
+    if constexpr (PERSIST) {
+        {
+            int lane_i = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            asm volatile("" : "+v"(lane_i));
+            lane_tables(lane_i);
+        }
+        if (!first_item) {
+            epilogue_persist((ph + (n_max - n_min) + 2) % 3);  // the previous item's O, through the V slot of the next item's tile 2
+            FA_PSTAMP(57);  // O stores issued
+            if (!has_next) break;
+            // ---- item switch: the rings hold the next item's K tiles 0..2 and V tiles 0, 1 (published by the barrier above), its
+            //      Q fragments are in registers; O and the softmax state start over.  (The O stores above are still in flight:
+            //      they are older than every LDS-DMA piece to come, so the counted vmcnt waits only ever over-wait for them.)
+            ph = __builtin_amdgcn_readfirstlane((ph + (n_max - n_min)) % 3);
+            m_block = m_block_n; head = head_n; batch = batch_n;
+            kv_head = head / p.h_ratio;
+            qp = (const T *)p.q + (int64_t)batch * p.q_batch_stride + (int64_t)head * p.q_head_stride;
+            kp = kp_n;
+            vp = vp_n;
+            op = (T *)p.o + (int64_t)batch * p.o_batch_stride + (int64_t)head * p.o_head_stride;
+            lse_base = ((int64_t)batch * p.h + head) * p.seqlen_q;
+            row_lo = m_block * BLOCK_M;
+            item_geometry();
+            {
+                const u32x4 z4 = {0, 0, 0, 0};
+#pragma unroll
+                for (int db = 0; db < DBLOCKS; ++db) {
+                    Mfma<T>::o_zero(oa[db], z4);
+                    Mfma<T>::o_zero(ob[db], z4);
+                }
+                asm volatile("s_nop 15\n\ts_nop 7" : "+a"(oa[0]), "+a"(oa[1]), "+a"(oa[2]), "+a"(oa[3]),
+                             "+a"(ob[0]), "+a"(ob[1]), "+a"(ob[2]), "+a"(ob[3]));
+            }
+            m_a = -INFINITY; m_b = -INFINITY;
+            l_a = 0.f; l_b = 0.f;
+#ifdef FA_CYCLES
+            ++fa_item;
+            FA_PSTAMP(55);  // item switch done: O stored (issued), state reset
+#endif
+        }
+        first_item = false;
+        // Q of the item to run now (first item: landed behind the prologue's barrier; later ones: prefetched during the previous
+        // sweep, landed behind its closing barrier) moves into the fragment registers, which frees the Q image for ...
+        q_fragments();
+        // ... the next item of the chain: its K / V heads for the look-ahead stream, its Q rows into the Q image
+        chain_next();
+        if (has_next) {
+            const int kv_head_n = head_n / p.h_ratio;
+            kp_n = (const T *)p.k + (int64_t)batch_n * p.k_batch_stride + (int64_t)kv_head_n * p.k_head_stride;
+            vp_n = (const T *)p.v + (int64_t)batch_n * p.v_batch_stride + (int64_t)kv_head_n * p.v_head_stride;
+            q_dma((const T *)p.q + (int64_t)batch_n * p.q_batch_stride + (int64_t)head_n * p.q_head_stride,
+                  m_block_n * BLOCK_M + wave * 64);
+        }
+        FA_PSTAMP(56);  // next item known, its Q requested; the first scores follow
+    }
     int in_flight = 0;                   // LDS-DMA pieces this wave issued at the top of the current tile
 
     // Pipeline state at the boundary in front of half-step j (canonical naming):
@@ -792,7 +1019,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     float alpha_a = 1.f, alpha_b = 1.f;
     bool moved_a = false, moved_b = false;
     if (jend > 0) {
-        qk_half_first(0, 1, sa, sbx);  // half-step 0 = second half of K tile n_min
+        qk_half_first(ph, 1, sa, sbx);  // half-step 0 = second half of K tile n_min
         drain_scores(sa, sbx);
         prep_scores(0, sa, sbx);
         softmax(sa, pax, m_a, l_a, alpha_a, moved_a);
@@ -812,12 +1039,12 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     bool redo_a = false;      // P_A(j) / l_a were produced with a stale max that turned out too small: redo from sa
     float l_a_saved = 0.f;
     auto generic_half = [&](int j) {
-        const int i = j >> 1, kb = j & 1, slot = i % 3, n = n_min + i;
+        const int i = j >> 1, kb = j & 1, slot = (i + ph) % 3, n = n_min + i;
         const int slot1 = slot == 2 ? 0 : slot + 1, slot2 = slot == 0 ? 2 : slot - 1;  // (slot+1)%3, (slot+2)%3
         if (kb == 0) {  // K tile n+3 over K tile n, V tile n+2 over V tile n-1 (both last read during tile n-1)
             in_flight = 0;
-            if (n + 3 <= n_max) { load_k(n + 3, slot); in_flight += LD_PER_THREAD; }
-            if (n + 2 < n_max) { load_v(n + 2, slot2); in_flight += LD_PER_THREAD; }
+            if (n + 3 <= n_max || (PERSIST && has_next)) { load_k(n + 3, slot); in_flight += LD_PER_THREAD; }
+            if (n + 2 < n_max || (PERSIST && has_next)) { load_v(n + 2, slot2); in_flight += LD_PER_THREAD; }
         }
         if (j < jend) {
             if (redo_a) {  // sa still holds S_A(j)
@@ -1056,15 +1283,52 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
                     for (int i = 0; i < 4; ++i) dsc[i] = __builtin_amdgcn_readfirstlane(dsc[i]);
                     return dsc;
                 };
-                const u32x4 kdesc = make_desc(kp, k_rs64), vdesc = make_desc(vp, v_rs64);
+                u32x4 kdesc, vdesc;
+                uint32_t ktile_nx = 0, vtile_nx = 0, kswc = ~0u, vswc = ~0u, ktile, vtile;
+                const uint32_t kstep = (uint32_t)(BLOCK_N * k_rs * 2), vstep = (uint32_t)(BLOCK_N * v_rs * 2);
+                if constexpr (PERSIST) {
+                    // One raw descriptor per tensor (the host checked: every byte offset fits 32 bits, seqlen_k is a multiple
+                    // of 64): an item is a byte offset, and the look-ahead stream switches to the next item's offset at the
+                    // tile step the generated block counts down to (kswc / vswc).  The K base lies 32 rows in front of the
+                    // tensor -- K tile m of a head starts 64 m - 32 rows behind the head's row 0 -- and only pieces whose lane
+                    // rows are >= 32 are ever issued for a tile 0 (the hybrid tile's second half: waves 2 and 3).
+                    auto tensor_desc = [&](const void *base, int64_t bs, int64_t hs, int64_t rs64, int64_t lead_rows) {
+                        const uint64_t b0 = (uint64_t)(uintptr_t)base - (uint64_t)(lead_rows * rs64 * 2);
+                        const int64_t extent = (int64_t)(p.b - 1) * bs + (int64_t)(p.h_k - 1) * hs + (int64_t)(sk - 1 + lead_rows) * rs64 + min(p.d, D);
+                        u32x4 dsc;
+                        dsc[0] = (uint32_t)b0;
+                        dsc[1] = (uint32_t)(b0 >> 32) & 0xffffu;
+                        dsc[2] = (uint32_t)(extent * 2);
+                        dsc[3] = 0x00020000u;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) dsc[i] = __builtin_amdgcn_readfirstlane(dsc[i]);
+                        return dsc;
+                    };
+                    kdesc = tensor_desc(p.k, p.k_batch_stride, p.k_head_stride, k_rs64, 32);
+                    vdesc = tensor_desc(p.v, p.v_batch_stride, p.v_head_stride, v_rs64, 0);
+                    const uint32_t koff_i = (uint32_t)((const char *)kp - (const char *)p.k), voff_i = (uint32_t)((const char *)vp - (const char *)p.v);
+                    const int mk = n_cur + 3, mv = n_cur + 2;       // the tiles the block's first step fetches
+                    ktile = koff_i + (uint32_t)mk * kstep;
+                    vtile = voff_i + (uint32_t)mv * vstep;
+                    if (has_next) {
+                        const int k_first = n_max + 1 - (wave >= 2 ? 1 : 0);  // first K tile index that is the next item's
+                        kswc = (uint32_t)max(0, k_first - mk);
+                        vswc = (uint32_t)max(0, n_max - mv);
+                        ktile_nx = (uint32_t)((const char *)kp_n - (const char *)p.k) + (uint32_t)(max(mk, k_first) - n_max) * kstep;
+                        vtile_nx = (uint32_t)((const char *)vp_n - (const char *)p.v) + (uint32_t)(max(mv, n_max) - n_max) * vstep;
+                    }
+                } else {
+                    kdesc = make_desc(kp, k_rs64);
+                    vdesc = make_desc(vp, v_rs64);
+                    ktile = (uint32_t)(((n_cur + 3) * BLOCK_N - 32) * k_rs * 2);
+                    vtile = (uint32_t)((n_cur + 2) * BLOCK_N * v_rs * 2);
+                }
                 uint32_t koffb[LD_PER_THREAD], voffb[LD_PER_THREAD];
 #pragma unroll
                 for (int i = 0; i < LD_PER_THREAD; ++i) {
                     koffb[i] = koff[i] - 1024u * i;
                     voffb[i] = voff[i] - 1024u * i;
                 }
-                const uint32_t ktile = (uint32_t)(((n_cur + 3) * BLOCK_N - 32) * k_rs * 2);
-                const uint32_t vtile = (uint32_t)((n_cur + 2) * BLOCK_N * v_rs * 2);
                 const float csc = csc_arg;
                 int done = 0, ra = 0, rb = 0;
                 uint64_t redo = 0;
@@ -1077,17 +1341,26 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
                 }
 #ifdef FA_CYCLES
                 unsigned long long *cb_ = (unsigned long long *)(smem + 6 * BLOCK_N * D * 2 + 1024) + (threadIdx.x >> 6) * 64;
-                if (!MASKED) { cb_[40] = __builtin_amdgcn_s_memtime(); cb_[42] = __builtin_amdgcn_s_memrealtime(); cb_[44] = count; }
+                if (!MASKED && !PERSIST) { cb_[40] = __builtin_amdgcn_s_memtime(); cb_[42] = __builtin_amdgcn_s_memrealtime(); cb_[44] = count; }
+                if (PERSIST) FA_PSTAMP(MASKED ? 44 : 42);
 #endif
+                if constexpr (PERSIST)
+                    FastLoop128P<T, MASKED>::run(oa, ob, qa, qb, sa, sbx, sby, pax, pay, l_a, l_b, l_a_saved,
+                                                 (m_a == -INFINITY ? 0.f : m_a) * csc, (m_b == -INFINITY ? 0.f : m_b) * csc, m_b,
+                                                 (uint32_t)kbase, (uint32_t)vbase, koffb, voffb, csc, THR / csc, LIM, kdesc,
+                                                 vdesc, ktile, vtile, kstep, vstep, lds0, lds_wave, ((j >> 1) + ph) % 3, count, done,
+                                                 redo, ra, rb, ktile_nx, vtile_nx, kswc, vswc);
+                else {
                 using Loop = std::conditional_t<D == 128, FastLoop128<T, DEFF, MASKED>, FastLoop64<T, MASKED>>;
                 Loop::run(oa, ob, qa, qb, sa, sbx, sby, pax, pay, l_a, l_b, l_a_saved,
                                                   (m_a == -INFINITY ? 0.f : m_a) * csc, (m_b == -INFINITY ? 0.f : m_b) * csc, m_b,
                                                   (uint32_t)kbase, (uint32_t)vbase, koffb, voffb, csc, THR / csc, LIM, kdesc,
-                                                  vdesc, ktile, vtile, (uint32_t)(BLOCK_N * k_rs * 2),
-                                                  (uint32_t)(BLOCK_N * v_rs * 2), lds0, lds_wave, (j >> 1) % 3, count, done,
+                                                  vdesc, ktile, vtile, kstep, vstep, lds0, lds_wave, ((j >> 1) + ph) % 3, count, done,
                                                   redo, ra, rb);
+                }
 #ifdef FA_CYCLES
-                if (!MASKED) { cb_[41] = __builtin_amdgcn_s_memtime(); cb_[43] = __builtin_amdgcn_s_memrealtime(); cb_[45] = done; }
+                if (!MASKED && !PERSIST) { cb_[41] = __builtin_amdgcn_s_memtime(); cb_[43] = __builtin_amdgcn_s_memrealtime(); cb_[45] = done; }
+                if (PERSIST) FA_PSTAMP(MASKED ? 45 : 43);
 #endif
                 j += done;
                 in_flight = 2 * LD_PER_THREAD;
@@ -1210,7 +1483,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     // dword of each of their cache lines here, with the whole epilogue (~3 us) in front of the end of this workgroup, turns
     // that into L2 hits.  The data lands in a 1 KiB dump area of LDS; dense batches only (no cu_seqlens lookups here).
     FA_STAMP(51);  // key sweep done
-    if (!p.cu_seqlens_q && !p.seqused_q && p.num_splits <= 1 && p.q_row_stride < (1 << 20)) {
+    if (!PERSIST && !p.cu_seqlens_q && !p.seqused_q && p.num_splits <= 1 && p.q_row_stride < (1 << 20)) {
         const int wg2 = blockIdx.x + p.num_cus;
         const int tile2 = tile_of_wg(p, wg2);
         if (wg2 < p.grid && tile2 < p.num_tiles) {
@@ -1229,81 +1502,90 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
         }
     }
     drain_all();        // asm MFMA results -> VALU readers
-    // lane constants are rebuilt from the lane id here: the ones computed in front of the main loop were spilled to
-    // scratch by then, and every reload is a separately awaited memory round trip (tools/wg_phases.py: 3.3 us epilogue)
-    const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    const int r_e = lane_e & 31, hh_e = lane_e >> 5;
-    const int row_a_e = wrow + r_e, row_b_e = wrow + 32 + r_e;
-    const float lt_a = half_swap_sum(l_a), lt_b = half_swap_sum(l_b);
-    const bool e_a = (lt_a == 0.f) || (lt_a != lt_a), e_b = (lt_b == 0.f) || (lt_b != lt_b);
-    const float inv_a = (e_a ? 1.f : 1.f / lt_a) * vdesc_e, inv_b = (e_b ? 1.f : 1.f / lt_b) * vdesc_e;
-    const bool wave_active = wrow < sq;
-    if (wave_active) {
-        if (hh_e == 0) {
-            if (row_a_e < sq) p.lse[lse_base + row_a_e] = e_a ? INFINITY : m_a * scale_e + __logf(lt_a);
-            if (row_b_e < sq) p.lse[lse_base + row_b_e] = e_b ? INFINITY : m_b * scale_e + __logf(lt_b);
-        }
-        if (p.num_splits > 1) {
-            // split-KV partial: fp32 in the caller's workspace (role of out_accum, csrc/flash_attn/flash_api.cpp:297-318), straight
-            // from the accumulators -- 4 consecutive head dims = one 16-byte store per lane; the merge launch rounds once
-            float *opf = (float *)p.o + o_base + (int64_t)head * p.o_head_stride;
+    if constexpr (!PERSIST) {
+        // ---- epilogue (inline at the end of the sweep: as a lambda defined in front of the item loop hipcc turned scalar
+        //      values of the prologue into vector ones and the asm operands that need them in SGPRs stopped assembling)
+        // lane constants are rebuilt from the lane id here: the ones computed in front of the main loop were spilled to
+        // scratch by then, and every reload is a separately awaited memory round trip (tools/wg_phases.py: 3.3 us epilogue)
+        int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        const int r_e = lane_e & 31, hh_e = lane_e >> 5;
+        const int row_a_e = wrow + r_e, row_b_e = wrow + 32 + r_e;
+        const float lt_a = half_swap_sum(l_a), lt_b = half_swap_sum(l_b);
+        const bool e_a = (lt_a == 0.f) || (lt_a != lt_a), e_b = (lt_b == 0.f) || (lt_b != lt_b);
+        const float inv_a = (e_a ? 1.f : 1.f / lt_a) * vdesc_e, inv_b = (e_b ? 1.f : 1.f / lt_b) * vdesc_e;
+        const bool wave_active = wrow < sq;
+        if (wave_active) {
+            if (hh_e == 0) {
+                if (row_a_e < sq) p.lse[lse_base + row_a_e] = e_a ? INFINITY : m_a * scale_e + __logf(lt_a);
+                if (row_b_e < sq) p.lse[lse_base + row_b_e] = e_b ? INFINITY : m_b * scale_e + __logf(lt_b);
+            }
+            if (!PERSIST && p.num_splits > 1) {
+                // split-KV partial: fp32 in the caller's workspace (role of out_accum, csrc/flash_attn/flash_api.cpp:297-318), straight
+                // from the accumulators -- 4 consecutive head dims = one 16-byte store per lane; the merge launch rounds once
+                float *opf = (float *)p.o + o_base + (int64_t)head * p.o_head_stride;
+#pragma unroll
+                for (int db = 0; db < DBLOCKS; ++db)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const int col = db * 32 + 8 * g4 + 4 * hh_e;
+                        if (col < p.d) {
+                            if (row_a_e < sq)
+                                *(float4 *)(opf + (int64_t)row_a_e * p.o_row_stride + col) =
+                                    make_float4(oa[db][4 * g4] * inv_a, oa[db][4 * g4 + 1] * inv_a, oa[db][4 * g4 + 2] * inv_a, oa[db][4 * g4 + 3] * inv_a);
+                            if (row_b_e < sq)
+                                *(float4 *)(opf + (int64_t)row_b_e * p.o_row_stride + col) =
+                                    make_float4(ob[db][4 * g4] * inv_b, ob[db][4 * g4 + 1] * inv_b, ob[db][4 * g4 + 2] * inv_b, ob[db][4 * g4 + 3] * inv_b);
+                        }
+                    }
+            } else {
+            // O staging: 64 rows per wave, padded rows inside the K/V rings (reused: the sweep is over)
+            char *obuf = smem + wave * (64 * O_ROW_BYTES);
 #pragma unroll
             for (int db = 0; db < DBLOCKS; ++db)
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
-                    const int col = db * 32 + 8 * g4 + 4 * hh_e;
-                    if (col < p.d) {
-                        if (row_a_e < sq)
-                            *(float4 *)(opf + (int64_t)row_a_e * p.o_row_stride + col) =
-                                make_float4(oa[db][4 * g4] * inv_a, oa[db][4 * g4 + 1] * inv_a, oa[db][4 * g4 + 2] * inv_a, oa[db][4 * g4 + 3] * inv_a);
-                        if (row_b_e < sq)
-                            *(float4 *)(opf + (int64_t)row_b_e * p.o_row_stride + col) =
-                                make_float4(ob[db][4 * g4] * inv_b, ob[db][4 * g4 + 1] * inv_b, ob[db][4 * g4 + 2] * inv_b, ob[db][4 * g4 + 3] * inv_b);
-                    }
+                    u32x2 wa, wb;
+                    wa[0] = Elem<T>::pack2(oa[db][4 * g4] * inv_a, oa[db][4 * g4 + 1] * inv_a);
+                    wa[1] = Elem<T>::pack2(oa[db][4 * g4 + 2] * inv_a, oa[db][4 * g4 + 3] * inv_a);
+                    wb[0] = Elem<T>::pack2(ob[db][4 * g4] * inv_b, ob[db][4 * g4 + 1] * inv_b);
+                    wb[1] = Elem<T>::pack2(ob[db][4 * g4 + 2] * inv_b, ob[db][4 * g4 + 3] * inv_b);
+                    const int col = (db * 32 + 8 * g4 + 4 * hh_e) * 2;
+                    *(u32x2 *)(obuf + r_e * O_ROW_BYTES + col) = wa;
+                    *(u32x2 *)(obuf + (32 + r_e) * O_ROW_BYTES + col) = wb;
                 }
-        } else {
-        char *obuf = smem + wave * (64 * O_ROW_BYTES);
-#pragma unroll
-        for (int db = 0; db < DBLOCKS; ++db)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                u32x2 wa, wb;
-                wa[0] = Elem<T>::pack2(oa[db][4 * g4] * inv_a, oa[db][4 * g4 + 1] * inv_a);
-                wa[1] = Elem<T>::pack2(oa[db][4 * g4 + 2] * inv_a, oa[db][4 * g4 + 3] * inv_a);
-                wb[0] = Elem<T>::pack2(ob[db][4 * g4] * inv_b, ob[db][4 * g4 + 1] * inv_b);
-                wb[1] = Elem<T>::pack2(ob[db][4 * g4 + 2] * inv_b, ob[db][4 * g4 + 3] * inv_b);
-                const int col = (db * 32 + 8 * g4 + 4 * hh_e) * 2;
-                *(u32x2 *)(obuf + r_e * O_ROW_BYTES + col) = wa;
-                *(u32x2 *)(obuf + (32 + r_e) * O_ROW_BYTES + col) = wb;
             }
         }
-    }
-    // (no workgroup barrier: a wave reads back only its own 64 staged rows, and LDS operations of one wave are in order)
-    FA_STAMP(52);  // O normalised and in LDS
-    if (wave_active && p.num_splits <= 1) {
-        const char *obuf = smem + wave * (64 * O_ROW_BYTES);
-        // (LDS reads outside the predicate: all of them are issued before the first store; inside it each read is
-        //  waited for in its own exec-masked block -- 16 serial LDS round trips at D = 128)
-        constexpr int NCH = (64 * CH_PER_ROW) / 64;
-        u32x4 val[NCH];
+        // (no workgroup barrier: a wave reads back only its own 64 staged rows, and LDS operations of one wave are in order)
+        FA_STAMP(52);  // O normalised and in LDS
+        if (wave_active && p.num_splits <= 1) {
+            const char *obuf = smem + wave * (64 * O_ROW_BYTES);
+            // (LDS reads outside the predicate: all of them are issued before the first store; inside it each read is
+            //  waited for in its own exec-masked block -- 16 serial LDS round trips at D = 128)
+            constexpr int NCH = (64 * CH_PER_ROW) / 64;
+            u32x4 val[NCH];
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int c = lane_e + i * 64;
-            val[i] = *(const u32x4 *)(obuf + (c / CH_PER_ROW) * O_ROW_BYTES + (c % CH_PER_ROW) * 16);
-        }
+            for (int i = 0; i < NCH; ++i) {
+                const int c = lane_e + i * 64;
+                val[i] = *(const u32x4 *)(obuf + (c / CH_PER_ROW) * O_ROW_BYTES + (c % CH_PER_ROW) * 16);
+            }
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int c = lane_e + i * 64;
-            const int row = c / CH_PER_ROW, ch = c % CH_PER_ROW;
-            if (wrow + row < sq && ch * 8 < p.d) *(u32x4 *)(op + (int64_t)(wrow + row) * p.o_row_stride + ch * 8) = val[i];
+            for (int i = 0; i < NCH; ++i) {
+                const int c = lane_e + i * 64;
+                const int row = c / CH_PER_ROW, ch = c % CH_PER_ROW;
+                if (wrow + row < sq && ch * 8 < p.d) *(u32x4 *)(op + (int64_t)(wrow + row) * p.o_row_stride + ch * 8) = val[i];
+            }
         }
+        break;
     }
+    }  // work items
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the prefetch's LDS-DMA has landed before this workgroup's LDS is released
 #ifdef FA_CYCLES
+    if constexpr (!PERSIST) {
     ((unsigned long long *)(smem + 6 * BLOCK_N * D * 2 + 1024))[(threadIdx.x >> 6) * 64 + 47] = __builtin_amdgcn_s_memrealtime();
     __syncthreads();
-    if (blockIdx.x >= FA_CYCLES_WG0 && blockIdx.x < FA_CYCLES_WG0 + 256)
-        fa_cycle_buf[(blockIdx.x - FA_CYCLES_WG0) * 256 + threadIdx.x] = ((unsigned long long *)(smem + 6 * BLOCK_N * D * 2 + 1024))[threadIdx.x];
+    if (blockIdx.x >= FA_CYCLES_WG0 && blockIdx.x < FA_CYCLES_WG0 + 256 * FA_CYCLES_STRIDE && (blockIdx.x - FA_CYCLES_WG0) % FA_CYCLES_STRIDE == 0)
+        fa_cycle_buf[(blockIdx.x - FA_CYCLES_WG0) / FA_CYCLES_STRIDE * 256 + threadIdx.x] = ((unsigned long long *)(smem + 6 * BLOCK_N * D * 2 + 1024))[threadIdx.x];
+    }
 #endif
 #ifdef FA_TIMING
     FA_T(6);

@@ -305,6 +305,9 @@ uint32_t fa_combine_params_size(void);
 
 /* Test hook: overrides the default kernel variant process-wide (0 = default). */
 void fa_set_default_variant(int32_t variant);
+/* Test hook: the persistent form of the 256-row kernel (one workgroup per CU walking a chain of work items):
+ * 0 = the library's choice, -1 = never, 1 = for every problem it can run (also chains of a single item). */
+void fa_set_persist_mode(int32_t mode);
 
 #ifdef __cplusplus
 }

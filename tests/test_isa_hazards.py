@@ -45,6 +45,13 @@ def test_no_unpadded_mfma_or_trans_hazards(tmp_path, unit):
             body = "\n".join(lines)
             i0, i1 = body.index(".Lf8_t0_"), body.rindex(".Lf8_exit_")
             assert body[i0:i1].count("v_mfma") == 96, name  # 6 unrolled tiles x 16
+        elif "fwd_kernel_w64" in name and name.endswith("ELb1EEEvNS_7KParamsE"):
+            # the persistent form (PERSIST = true): hipcc keeps a few item-level values in scratch around the item switch; none
+            # inside the generated blocks (the labels .Lfa_t0 .. .Lfa_exit bracket each one)
+            body = "\n".join(lines)
+            for blk in re.findall(r"\.Lfa_in1_\d+:.*?\.Lfa_exit_\d+:", body, re.S):
+                assert "scratch_" not in blk, name
+                assert blk.count("v_mfma") >= 3 * 64, name
         elif "fwd_kernel_w64" in name or "fwd_kernel_d256" in name:
             assert any_scratch == 0, (name, any_scratch)
         elif "fwd_kernel" in name:

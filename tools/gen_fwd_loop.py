@@ -31,6 +31,11 @@ KSTEPS = DEFF // 16         # k-steps of the QK^T product (8 or 6)
 NSTEP = 2 * (DEFF // 32)    # (db, st) steps of the PV product (8 or 6)
 NPAIRS = 8                  # score pairs per 32x32 block and lane
 MASKED = False              # variant with the causal / right-window / end-of-sequence mask applied to the fresh scores
+# PERSIST (FastLoop128P, the persistent kernel): the K / V look-ahead stream runs on into the NEXT work item's first tiles.
+# One raw descriptor spans the whole K (V) tensor, so an item is just a byte offset: at the tile step where `kswc` (`vswc`)
+# reaches zero the source offset `ktile` (`vtile`) is replaced by `ktile_nx` (`vtile_nx`); 3 scalar instructions per tile each.
+PERSIST = False
+FIXED_AGPR = False   # (tried: fixed AGPR homes for O / Q in the persistent loop made hipcc's allocation worse, not better)
 
 
 def keyoff(i):
@@ -204,6 +209,10 @@ def gen_half(E, slot, KB, uid):
                         E.e(f"s_add_u32 m0, %[lds_wave], {kdst}")
                     E.wait_for(tag_of(ks))   # (no-op when an earlier `wn` covered it)
                 E.e(f"{mf} {v(SA, 16)}, {v(kf(ks), 4)}, %[qa{ks}], {c_a}")
+                if PERSIST and KB == 0 and ks == 0:
+                    E.e("s_cmp_eq_u32 %[kswc], 0")
+                    E.e("s_cselect_b32 %[ktile], %[ktile_nx], %[ktile]")
+                    E.e("s_sub_u32 %[kswc], %[kswc], 1")
                 if KB == 0 and ks < LD and not (ABLATE & 1):
                     # piece ks of K tile n+3: 1 KiB at M0 + 1024 ks (the instruction offset moves the LDS target AND the source:
                     # the lane offsets carry -1024 ks); rows past the end of the sequence read as zeros (raw buffer, num_records)
@@ -273,6 +282,10 @@ def gen_half(E, slot, KB, uid):
                         E.e(f"s_add_u32 m0, %[lds_wave], {vdst}")
                     E.wait_for(tag_of(KSTEPS + t))
                 E.e(f"{mf} %[oa{db}], {v(vf(t), 4)}, {v(pa_cur + 4 * st, 4)}, %[oa{db}]")
+                if PERSIST and KB == 0 and t == 0:
+                    E.e("s_cmp_eq_u32 %[vswc], 0")
+                    E.e("s_cselect_b32 %[vtile], %[vtile_nx], %[vtile]")
+                    E.e("s_sub_u32 %[vswc], %[vswc], 1")
                 if KB == 0 and t < LD and not (ABLATE & 1):
                     E.e(f"buffer_load_dwordx4 {v(VOFF + t)}, %[vdesc], %[vtile] offen offset:{1024 * t} lds")
                 if MASKED and t == 0:
@@ -402,6 +415,7 @@ HEADER = '''// GENERATED by tools/gen_fwd_loop.py -- do not edit; regenerate wit
 namespace fa {
 
 template <typename T, int DEFF, bool MASKED = false> struct FastLoop128;
+template <typename T, bool MASKED = false> struct FastLoop128P;  // DEFF = 128 with the item switch of the persistent kernel (PERSIST in the generator)
 template <typename T, bool MASKED = false> struct FastLoop64;  // head-dim tile 64 (LDS rows of 128 B, 4 k-steps, 2 O blocks, 2 LDS-DMA pieces per wave)
 // DEFF: head dims contracted / produced (128, or 96: zero padding skipped).  MASKED: the fresh scores S_A(j+1) / S_B(j+1) get
 // the causal / right-window / end-of-sequence mask (key > limit -> -inf; ra / rb = the lane's last visible key minus the key
@@ -415,7 +429,7 @@ FUNC = '''template <> struct %(STRUCT)s {
                                                const uint32_t (&koff)[%(LD)d], const uint32_t (&voff)[%(LD)d], float csc, float thr_c,
                                                float lim, u32x4 kdesc, u32x4 vdesc, uint32_t ktile, uint32_t vtile,
                                                uint32_t kstep, uint32_t vstep, uint32_t lds0, uint32_t lds_wave, int slot0,
-                                               int &count, int &done, uint64_t &redo, int ra = 0, int rb = 0) {
+                                               int &count, int &done, uint64_t &redo, int ra = 0, int rb = 0%(pargs)s) {
         uint32_t m0save;
         uint64_t bflag;
         const uint32_t lds0v = lds0 + %(vregion)d;
@@ -426,12 +440,12 @@ FUNC = '''template <> struct %(STRUCT)s {
               "+{v[48:51]}"(pax[0]), "+{v[52:55]}"(pax[1]), "+{v[56:59]}"(pay[0]), "+{v[60:63]}"(pay[1]),
               "+{v122}"(l_a), "+{v123}"(l_b), "+{v124}"(l_a_saved),
               [ktile] "+s"(ktile), [vtile] "+s"(vtile),
-              [count] "+s"(count), [done] "+s"(done), [redo] "=&s"(redo), [bflag] "=&s"(bflag), [m0save] "=&s"(m0save)%(maskout)s
+              [count] "+s"(count), [done] "+s"(done), [redo] "=&s"(redo), [bflag] "=&s"(bflag), [m0save] "=&s"(m0save)%(maskout)s%(pout)s
             : "{v120}"(mca), "{v121}"(mcb), "{v125}"(m_b), "{v136}"(m_b + thr_c), "{v134}"(kbase), "{v135}"(vbase),
               %(offs)s,
               [csc] "s"(csc), [lim] "s"(lim), [kstep] "s"(kstep), [vstep] "s"(vstep),
               [kdesc] "s"(kdesc), [vdesc] "s"(vdesc),
-              [lds0] "s"(lds0), [lds0v] "s"(lds0v), [lds_wave] "s"(lds_wave), [slot0] "s"(slot0)
+              [lds0] "s"(lds0), [lds0v] "s"(lds0v), [lds_wave] "s"(lds_wave), [slot0] "s"(slot0)%(pin)s
             : "memory", "vcc", "scc"%(clobbers)s);
     }
 };
@@ -439,8 +453,15 @@ FUNC = '''template <> struct %(STRUCT)s {
 
 
 def operands(ndb, nks, ld):
-    accs = [f'[oa{i}] "+a"(oa[{i}])' for i in range(ndb)] + [f'[ob{i}] "+a"(ob[{i}])' for i in range(ndb)]
-    accs += [f'[qa{i}] "+a"(qa[{i}])' for i in range(nks)] + [f'[qb{i}] "+a"(qb[{i}])' for i in range(nks)]
+    if PERSIST and FIXED_AGPR:
+        # fixed AGPR homes: inside the item loop of the persistent kernel hipcc otherwise moves the accumulators and the Q
+        # fragments between AGPR tuples from one asm statement to the next (copies through VGPRs, spills to scratch)
+        fx = lambda base, i, n: f'"+{{a[{base + n * i}:{base + n * i + n - 1}]}}"'
+        accs = [f'[oa{i}] {fx(OA, i, 16)}(oa[{i}])' for i in range(ndb)] + [f'[ob{i}] {fx(OB, i, 16)}(ob[{i}])' for i in range(ndb)]
+        accs += [f'[qa{i}] {fx(QA, i, 4)}(qa[{i}])' for i in range(nks)] + [f'[qb{i}] {fx(QB, i, 4)}(qb[{i}])' for i in range(nks)]
+    else:
+        accs = [f'[oa{i}] "+a"(oa[{i}])' for i in range(ndb)] + [f'[ob{i}] "+a"(ob[{i}])' for i in range(ndb)]
+        accs += [f'[qa{i}] "+a"(qa[{i}])' for i in range(nks)] + [f'[qb{i}] "+a"(qb[{i}])' for i in range(nks)]
     offs = [f'"{{v{KOFF + i}}}"(koff[{i}])' for i in range(ld)] + [f'"{{v{VOFF + i}}}"(voff[{i}])' for i in range(ld)]
     join = lambda xs: (",\n              ".join(", ".join(xs[i:i + 4]) for i in range(0, len(xs), 4)))
     return join(accs), join(offs)
@@ -469,13 +490,15 @@ def main():
         globals()["SLICE"] = sys.argv[sys.argv.index("--slice") + 1].replace("_", " ")
     if "--out" in sys.argv:
         path = sys.argv[sys.argv.index("--out") + 1]
-    global D, ROWB, TILE, LD, DEFF, KSTEPS, NSTEP, MASKED, KF, VF
+    global D, ROWB, TILE, LD, DEFF, KSTEPS, NSTEP, MASKED, KF, VF, PERSIST
     if FD == 3:
         KF, VF = 156, 172   # 4 x 4 each
     text = HEADER
     # (head-dim tile, dims contracted, masked variant?)
-    configs = [(128, 128, False), (128, 96, False), (128, 128, True), (128, 96, True), (64, 64, False), (64, 64, True)]
-    for d, deff, masked in configs:
+    configs = [(128, 128, False, False), (128, 96, False, False), (128, 128, True, False), (128, 96, True, False), (64, 64, False, False),
+               (64, 64, True, False), (128, 128, False, True), (128, 128, True, True)]
+    for d, deff, masked, persist in configs:
+        PERSIST = persist
         D, ROWB, TILE, LD = d, d * 2, 64 * d * 2, d // 32
         DEFF, KSTEPS, NSTEP, MASKED = deff, deff // 16, 2 * (deff // 32), masked
         unused = [KOFF + i for i in range(LD, 4)] + [VOFF + i for i in range(LD, 4)]  # (no inputs there at LD = 2)
@@ -485,9 +508,14 @@ def main():
             accs, offs = operands(d // 32, d // 16, LD)
             struct = (f"FastLoop128<{T}, {deff}, {'true' if masked else 'false'}>" if d == 128 else
                       f"FastLoop64<{T}, {'true' if masked else 'false'}>")
+            if persist:
+                struct = f"FastLoop128P<{T}, {'true' if masked else 'false'}>"
             text += "\n" + FUNC % {"STRUCT": struct, "NDB": d // 32, "NKS": d // 16, "LD": LD, "accs": accs, "offs": offs,
                                    "body": render(lines), "clobbers": clob + (', "v139"' if masked else ""),
-                                   "vregion": 3 * TILE, "maskout": ', "+{v137}"(ra), "+{v138}"(rb)' if masked else ""}
+                                   "vregion": 3 * TILE, "maskout": ', "+{v137}"(ra), "+{v138}"(rb)' if masked else "",
+                                   "pargs": ", uint32_t ktile_nx = 0, uint32_t vtile_nx = 0, uint32_t kswc = ~0u, uint32_t vswc = ~0u" if persist else "",
+                                   "pout": ', [kswc] "+s"(kswc), [vswc] "+s"(vswc)' if persist else "",
+                                   "pin": ', [ktile_nx] "s"(ktile_nx), [vtile_nx] "s"(vtile_nx)' if persist else ""}
     text += "\n}  // namespace fa\n"
     if "--check" in sys.argv:
         sys.exit(0 if os.path.exists(path) and open(path).read() == text else 1)
