@@ -538,6 +538,8 @@ bool persist_ok(const fa::KParams &kp) {
     if (kp.d <= 96 || kp.d > 128 || kp.window_left >= 0) return false;
     if (kp.seqlen_k % 64 != 0 || kp.seqlen_k < 192 || kp.seqlen_q > kp.seqlen_k) return false;  // (causal: bottom-right aligned, shift >= 0)
     if ((kp.num_cus & ~7) < 8) return false;
+    // the kernel decodes its chain once into 32-bit entries (m_block 12 bits, head 10, batch 10), one lane per round
+    if (kp.grid > 64 * (kp.num_cus & ~7) || kp.num_m_blocks > 4096 || kp.h > 1024 || kp.b > 1024) return false;
     auto extent = [&](int64_t bs, int64_t hs, int64_t rs, int lead) {
         return ((int64_t)(kp.b - 1) * bs + (int64_t)(kp.h_k - 1) * hs + (int64_t)(kp.seqlen_k - 1 + lead) * rs + 128) * 2;
     };

@@ -495,27 +495,40 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     bool has_next = false;
     int m_block_n = 0, head_n = 0, batch_n = 0;
     const T *kp_n = kp, *vp_n = vp;
-    auto chain_next = [&]() {  // (m_block_n, head_n, batch_n) of the next valid item of the chain, or has_next = false
+    // The chain is decoded once, lane t = round t (the host keeps chains at <= 64 rounds and every field inside its bits):
+    // m_block << 20 | head << 10 | batch, or ~0 for a round without an item for this CU.  In the item loop a round is one
+    // v_readlane -- the integer divisions of the decode (VALU reciprocals hipcc would hoist and keep alive across every
+    // asm block, i.e. spill) happen here, for all rounds at once.
+    uint32_t chain_tbl = ~0u;
+    if constexpr (PERSIST) {
         const int cpx = (int)gridDim.x >> 3, k = (int)blockIdx.x >> 3, xcd = (int)blockIdx.x & 7;
-        has_next = false;
-        for (int t = chain_round + 1;; ++t) {
-            const int slot = cpx * t + ((t & 1) ? cpx - 1 - k : k);
-            if (cpx * t * 8 >= p.grid) break;           // the whole round lies behind the slot list
-            const int wg = slot * 8 + xcd;
-            if (wg >= p.grid) continue;
+        const int t = lane;
+        const int slot = cpx * t + ((t & 1) ? cpx - 1 - k : k);
+        const int wg = slot * 8 + xcd;
+        if (cpx * t * 8 < p.grid && wg < p.grid) {
             const int tile = tile_of_wg(p, wg);
-            if (tile >= p.num_tiles) continue;
-            const int per_kvh = p.h_ratio * p.num_m_blocks;
-            const int bk = tile / per_kvh, r2 = tile % per_kvh;
-            batch_n = __builtin_amdgcn_readfirstlane(bk / p.h_k);
-            m_block_n = __builtin_amdgcn_readfirstlane(p.num_m_blocks - 1 - r2 / p.h_ratio);
-            head_n = __builtin_amdgcn_readfirstlane((bk % p.h_k) * p.h_ratio + r2 % p.h_ratio);
+            if (tile < p.num_tiles) {
+                const int per_kvh = p.h_ratio * p.num_m_blocks;
+                const int bk = tile / per_kvh, r2 = tile % per_kvh;
+                chain_tbl = (uint32_t)(p.num_m_blocks - 1 - r2 / p.h_ratio) << 20 | (uint32_t)((bk % p.h_k) * p.h_ratio + r2 % p.h_ratio) << 10 |
+                            (uint32_t)(bk / p.h_k);
+            }
+        }
+    }
+    auto chain_next = [&]() {  // (m_block_n, head_n, batch_n) of the next item of the chain, or has_next = false
+        has_next = false;
+        const int rounds = (p.grid + (int)gridDim.x - 1) / (int)gridDim.x;  // (<= 64)
+        for (int t = chain_round + 1; t < rounds; ++t) {
+            const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)chain_tbl, t);
+            if (e == ~0u) continue;
+            batch_n = (int)(e & 1023u);
+            head_n = (int)((e >> 10) & 1023u);
+            m_block_n = (int)(e >> 20);
             chain_round = t;
             has_next = true;
             break;
         }
     };
-
     // The few kernel arguments the main loop needs, detached from the kernarg SGPR tuples (hipcc loads the by-value
     // struct as s_load_dwordx8/x16 tuples and, once those spill, reloads a whole tuple through v_readlane -- VALU
     // instructions -- every tile just to reach one field).  The empty asm makes each one a fresh scalar value.
@@ -732,7 +745,8 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
         // (both branches rebuild their lane constants from the lane id: kept live across the main loop they are spilled
         //  to scratch, and the reload is a memory round trip in front of every masked half-step)
         if (p.alibi) {  // wave-uniform; bias on the (soft-capped) score, before masking: src/mask.h:156-186
-            const int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            if constexpr (PERSIST) asm volatile("" : "+v"(ln));  // (not hoisted out of the item loop: see lane_tables)
             const int k0 = n_min * BLOCK_N + 32 * j + 4 * (ln >> 5);
             const int rel_a = wrow + (ln & 31) + shift - k0, rel_b = rel_a + 32;
 #pragma unroll
@@ -743,7 +757,8 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
             }
         }
         if (half_needs_mask(j)) {
-            const int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            if constexpr (PERSIST) asm volatile("" : "+v"(ln));  // (not hoisted out of the item loop: see lane_tables)
             const int k0 = n_min * BLOCK_N + 32 * j + 4 * (ln >> 5);
             const int ra = wrow + (ln & 31) + shift, rb = ra + 32;  // diagonal key of this lane's rows
             int hi_a = sk, hi_b = sk, lo_a = 0, lo_b = 0;  // [lo, hi) visible
@@ -890,13 +905,13 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
 #ifdef FA_CYCLES
     int fa_item = 0;
 #endif
-    // PERSIST: at an item switch the rings hold the next item's first tiles and the Q image its Q -- what is free is the V
-    // ring slot the next sweep's first tile fills (V tile 2 of the next item), and of that slot each wave owns the 4 KiB its
-    // own LDS-DMA pieces go to.  O is staged there in four passes of 16 rows (q-block A rows 0..15, 16..31, then B): unpadded
-    // 256-byte rows, 16-byte chunk c of row r at chunk slot c ^ r.  Wave-private and in order: no barrier, and the wave's
-    // next LDS-DMA into the region is issued after its last read of it has returned.
-    auto epilogue_persist = [&](int vslot) {
-        if constexpr (PERSIST) {
+    // PERSIST: at an item switch the rings hold the next item's first tiles and the Q image its Q: no LDS to stage O through.
+    // O leaves straight from the accumulators: lane (row r, half hh) holds 4 consecutive head dims of every 8 (dims 8 c + 4 hh
+    // ..); one v_permlane32_swap per packed dword between the registers of chunks c and c + 1 gives lane (r, hh) all 8 dims of
+    // chunk c + hh -- 16 bytes, one buffer store: a store instruction writes 32 bytes of each of 32 rows (whole 32-byte
+    // sectors, merged to full lines in L2).  The raw descriptor covers this wave's rows: rows past the end of q and chunks
+    // past d fall to the range check -- no predicates, no 64-bit lane addresses.
+    auto epilogue_persist = [&]() {
         int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
         asm volatile("" : "+v"(lane_e));  // (not hoisted out of the item loop: see lane_tables)
         const int r_e = lane_e & 31, hh_e = lane_e >> 5;
@@ -909,45 +924,30 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
             if (row_a_e < sq) p.lse[lse_base + row_a_e] = e_a ? INFINITY : m_a * scale_e + __logf(lt_a);
             if (row_b_e < sq) p.lse[lse_base + row_b_e] = e_b ? INFINITY : m_b * scale_e + __logf(lt_b);
         }
-        char *obuf = smem + (3 + vslot) * TILE_BYTES + wave * (LD_PER_THREAD * 1024);
-        const int wr_off = (r_e & 15) * ROWB + 8 * hh_e;  // this lane's row inside a pass
-        const int rd_row = lane_e >> 4, rd_ch = lane_e & 15;  // read-back: lane -> (row rd_row + 4 i, chunk rd_ch)
+        const int rows_here = min(sq - wrow, 64);
+        const __amdgpu_buffer_rsrc_t odesc = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(op + (int64_t)wrow * p.o_row_stride), 0,
+            (int)(((int64_t)(rows_here - 1) * p.o_row_stride + min(p.d, D)) * 2), 0x00020000);
+        const uint32_t o_rs2 = (uint32_t)p.o_row_stride * 2u;
+        const uint32_t off_a = (uint32_t)r_e * o_rs2 + (uint32_t)hh_e * 16u, off_b = off_a + 32u * o_rs2;
+        auto put = [&](const f32x16 &o, int db, int g4, float inv, uint32_t row_off) {  // chunks 4 db + g4 and + 1 (g4 even)
+            const uint32_t x0 = Elem<T>::pack2(o[4 * g4] * inv, o[4 * g4 + 1] * inv), x1 = Elem<T>::pack2(o[4 * g4 + 2] * inv, o[4 * g4 + 3] * inv);
+            const uint32_t y0 = Elem<T>::pack2(o[4 * g4 + 4] * inv, o[4 * g4 + 5] * inv), y1 = Elem<T>::pack2(o[4 * g4 + 6] * inv, o[4 * g4 + 7] * inv);
+            // upper lanes of x <-> lower lanes of y: (r, 0) ends with its own half and (r, 1)'s of chunk c, (r, 1) with both of c + 1
+            const auto s0 = __builtin_amdgcn_permlane32_swap(x0, y0, false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(x1, y1, false, false);
+            const u32x4 v4 = {s0[0], s1[0], s0[1], s1[1]};
+            const int ch = 4 * db + g4 + hh_e;
+            const uint32_t off = ch * 8 < p.d ? row_off + (uint32_t)(4 * db + g4) * 16u : 0x7ffffff0u;
+            __builtin_amdgcn_raw_buffer_store_b128(v4, odesc, off, 0, 0);
+        };
 #pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
-            if ((r_e >> 4) == (pass & 1)) {
+        for (int db = 0; db < DBLOCKS; ++db)
 #pragma unroll
-                for (int db = 0; db < DBLOCKS; ++db)
-#pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) {
-                        u32x2 w;
-                        if (pass < 2) {
-                            w[0] = Elem<T>::pack2(oa[db][4 * g4] * inv_a, oa[db][4 * g4 + 1] * inv_a);
-                            w[1] = Elem<T>::pack2(oa[db][4 * g4 + 2] * inv_a, oa[db][4 * g4 + 3] * inv_a);
-                        } else {
-                            w[0] = Elem<T>::pack2(ob[db][4 * g4] * inv_b, ob[db][4 * g4 + 1] * inv_b);
-                            w[1] = Elem<T>::pack2(ob[db][4 * g4 + 2] * inv_b, ob[db][4 * g4 + 3] * inv_b);
-                        }
-                        *(u32x2 *)(obuf + wr_off + (((db * 4 + g4) ^ (r_e & 15)) * 16)) = w;
-                    }
+            for (int g4 = 0; g4 < 4; g4 += 2) {
+                put(oa[db], db, g4, inv_a, off_a);
+                put(ob[db], db, g4, inv_b, off_b);
             }
-            // (compiler barrier: the 8-byte stores and the 16-byte loads are different vector types, which type-based alias
-            //  analysis lets hipcc reorder -- rows then came back with the previous pass's content; the hardware keeps a wave's
-            //  LDS operations in order)
-            asm volatile("" ::: "memory");
-            u32x4 val[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = rd_row + 4 * i;
-                val[i] = *(const u32x4 *)(obuf + row * ROWB + ((rd_ch ^ row) * 16));
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = wrow + 16 * pass + rd_row + 4 * i;
-                if (row < sq && rd_ch * 8 < p.d) *(u32x4 *)(op + (int64_t)row * p.o_row_stride + rd_ch * 8) = val[i];
-            }
-            asm volatile("" ::: "memory");  // (the next pass's stores stay behind this pass's loads)
-        }
-        }
     };
     bool first_item = true;
     for (int it_ = 0; PERSIST || it_ < 1; ++it_) {  // work items of this workgroup (exactly one unless PERSIST)
@@ -958,7 +958,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
             lane_tables(lane_i);
         }
         if (!first_item) {
-            epilogue_persist((ph + (n_max - n_min) + 2) % 3);  // the previous item's O, through the V slot of the next item's tile 2
+            epilogue_persist();  // the previous item's O and LSE
             FA_PSTAMP(57);  // O stores issued
             if (!has_next) break;
             // ---- item switch: the rings hold the next item's K tiles 0..2 and V tiles 0, 1 (published by the barrier above), its
@@ -1333,7 +1333,8 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
                 int done = 0, ra = 0, rb = 0;
                 uint64_t redo = 0;
                 if constexpr (MASKED) {  // last visible key of this lane's rows, relative to the key base of S(j+1) in its lane half
-                    const int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+                    int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+                    if constexpr (PERSIST) asm volatile("" : "+v"(ln));  // (not hoisted out of the item loop: see lane_tables)
                     const int kb1 = n_min * BLOCK_N + 32 * (j + 1) + 4 * (ln >> 5);
                     const int row = wrow + (ln & 31) + shift;
                     ra = (p.window_right >= 0 ? min(sk - 1, row + p.window_right) : sk - 1) - kb1;
@@ -1344,10 +1345,14 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
                 if (!MASKED && !PERSIST) { cb_[40] = __builtin_amdgcn_s_memtime(); cb_[42] = __builtin_amdgcn_s_memrealtime(); cb_[44] = count; }
                 if (PERSIST) FA_PSTAMP(MASKED ? 44 : 42);
 #endif
+                // (PERSIST: THR / c from an opaque copy of c -- as a loop invariant of the item loop hipcc keeps the quotient in
+                //  a spilled register, and its reload in front of every block waits for the Q prefetch, vmcnt(0))
+                float csc_q = csc;
+                if constexpr (PERSIST) asm volatile("" : "+s"(csc_q));
                 if constexpr (PERSIST)
                     FastLoop128P<T, MASKED>::run(oa, ob, qa, qb, sa, sbx, sby, pax, pay, l_a, l_b, l_a_saved,
                                                  (m_a == -INFINITY ? 0.f : m_a) * csc, (m_b == -INFINITY ? 0.f : m_b) * csc, m_b,
-                                                 (uint32_t)kbase, (uint32_t)vbase, koffb, voffb, csc, THR / csc, LIM, kdesc,
+                                                 (uint32_t)kbase, (uint32_t)vbase, koffb, voffb, csc, THR / csc_q, LIM, kdesc,
                                                  vdesc, ktile, vtile, kstep, vstep, lds0, lds_wave, ((j >> 1) + ph) % 3, count, done,
                                                  redo, ra, rb, ktile_nx, vtile_nx, kswc, vswc);
                 else {
@@ -1493,7 +1498,8 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
             const int head2 = (bk2 % p.h_k) * p.h_ratio + r2 % p.h_ratio;
             const T *q2 = (const T *)p.q + (int64_t)(bk2 / p.h_k) * p.q_batch_stride + (int64_t)head2 * p.q_head_stride +
                           (int64_t)(m_block2 * BLOCK_M) * p.q_row_stride;  // wave-uniform
-            const int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            if constexpr (PERSIST) asm volatile("" : "+v"(ln));  // (not hoisted out of the item loop: see lane_tables)
             const int row2 = min(wave * 64 + ln, p.seqlen_q - 1 - m_block2 * BLOCK_M);  // row inside the block, clamped
             const uint32_t off2 = (uint32_t)(row2 * (int)p.q_row_stride) * 2u;
             const uint32_t dump = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem + 6 * BLOCK_N * D * 2 + wave * 256;
