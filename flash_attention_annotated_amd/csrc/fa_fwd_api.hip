@@ -547,9 +547,10 @@ bool persist_ok(const fa::KParams &kp) {
     if (extent(kp.k_batch_stride, kp.k_head_stride, kp.k_row_stride, 32) >= (1ll << 32) - 65536 ||
         extent(kp.v_batch_stride, kp.v_head_stride, kp.v_row_stride, 0) >= (1ll << 32) - 65536) return false;
     if ((int64_t)kp.seqlen_k * kp.k_row_stride >= (1ll << 30) || (int64_t)kp.seqlen_k * kp.v_row_stride >= (1ll << 30)) return false;
-    // (mode 0: off for now -- correct and bit-identical, but an item switch still costs more than a workgroup hand-over:
-    //  profiles/r3_persist.txt; fa_set_persist_mode(1) turns it on for every problem it can run)
-    return mode > 0;
+    if (mode > 0) return true;
+    // chains of one item gain nothing; from two items per CU on the persistent form wins or ties on the whole benchmark grid
+    // (profiles/r3_persist_sweep.txt: non-causal s512 .. 16k +10 / +5 / +2 / 0 %, causal +21 / +26 / +15 / +11 / +3 / +1 %)
+    return kp.grid > (kp.num_cus & ~7);
 }
 
 // head dims 129 .. 256, plain features: 4 waves x 32 rows around the generated loop FastLoop256 (fa_fwd_kernel_d256.h)

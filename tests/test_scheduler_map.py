@@ -63,3 +63,38 @@ def test_backward_block_map(units, blocks):
             per_xcd[xcd] += 1
     assert sorted(seen) == list(range(tiles))
     assert max(per_xcd) - min(per_xcd) <= 1
+
+
+@pytest.mark.parametrize("b,h_k,h_ratio,m,cus", [(4, 16, 1, 32, 256), (32, 16, 1, 2, 256), (8, 16, 1, 8, 256), (2, 21, 1, 32, 256),
+                                                 (3, 7, 2, 9, 64), (8, 8, 4, 5, 256), (1, 40, 1, 3, 104), (4, 16, 1, 64, 256)])
+def test_persistent_chains_cover_every_tile_once(b, h_k, h_ratio, m, cus):
+    """The persistent form of the 256-row kernel (fwd_kernel_w64<.., PERSIST>, role of hopper/tile_scheduler.hpp:140-214): one
+    workgroup per CU, round t of the CU with index k inside its XCD takes slot cpx t + k of the XCD's slot list, odd rounds in
+    reverse.  Every valid tile is taken by exactly one workgroup, a chain stays on one XCD, a chain has at most 64 rounds
+    whenever the host lets the form run, and under a causal mask (cost ~ m_block + 1) the zig-zag keeps the chains of an XCD
+    within two items' worth of each other."""
+    tiles, unit_tiles, whole_slots, grid = host(b, h_k, h_ratio, m)
+    wgs = min(grid, cus & ~7)
+    cpx = wgs >> 3
+    rounds = (grid + wgs - 1) // wgs
+    seen, cost = [], {}
+    for wg0 in range(wgs):
+        k, xcd = wg0 >> 3, wg0 & 7
+        for t in range(rounds):
+            slot = cpx * t + (cpx - 1 - k if t & 1 else k)
+            wg = slot * 8 + xcd
+            if cpx * t * 8 >= grid or wg >= grid:
+                continue
+            tile = tile_of_wg(wg, unit_tiles, whole_slots, h_ratio)
+            if tile >= tiles:
+                continue
+            seen.append(tile)
+            m_block = m - 1 - (tile % unit_tiles) // h_ratio
+            cost[wg0] = cost.get(wg0, 0) + m_block + 1
+    assert sorted(seen) == list(range(tiles))
+    if grid <= 64 * wgs:
+        assert rounds <= 64
+    if rounds >= 2 and rounds % 2 == 0 and whole_slots * 8 == grid:
+        for xcd in range(8):
+            c = [cost.get(k * 8 + xcd, 0) for k in range(cpx)]
+            assert max(c) - min(c) <= 2 * m, (xcd, c)
