@@ -911,6 +911,9 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     // chunk c + hh -- 16 bytes, one buffer store: a store instruction writes 32 bytes of each of 32 rows (whole 32-byte
     // sectors, merged to full lines in L2).  The raw descriptor covers this wave's rows: rows past the end of q and chunks
     // past d fall to the range check -- no predicates, no 64-bit lane addresses.
+    // (The 16 stores are what the epilogue waits for: ~0.7 us of packing, ~1.1 us of the memory pipe pushing back, 32 row
+    //  segments per instruction.  Spreading them over the item switch -- four at a time between the Q fragment reads, the
+    //  decode and the Q prefetch -- was measured worse, 7.5 -> 8.9 us per switch: the prefetch then queues behind them.)
     auto epilogue_persist = [&]() {
         int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
         asm volatile("" : "+v"(lane_e));  // (not hoisted out of the item loop: see lane_tables)
@@ -924,6 +927,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
             if (row_a_e < sq) p.lse[lse_base + row_a_e] = e_a ? INFINITY : m_a * scale_e + __logf(lt_a);
             if (row_b_e < sq) p.lse[lse_base + row_b_e] = e_b ? INFINITY : m_b * scale_e + __logf(lt_b);
         }
+        FA_PSTAMP(58);  // LSE written
         const int rows_here = min(sq - wrow, 64);
         const __amdgpu_buffer_rsrc_t odesc = __builtin_amdgcn_make_buffer_rsrc(
             (void *)(op + (int64_t)wrow * p.o_row_stride), 0,
@@ -939,7 +943,11 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
             const u32x4 v4 = {s0[0], s1[0], s0[1], s1[1]};
             const int ch = 4 * db + g4 + hh_e;
             const uint32_t off = ch * 8 < p.d ? row_off + (uint32_t)(4 * db + g4) * 16u : 0x7ffffff0u;
+#ifdef FA_EPI_ABLATE_STORES   // developer-only timing ablation (results are WRONG): the epilogue without its stores
+            asm volatile("" :: "v"(v4), "v"(off));
+#else
             __builtin_amdgcn_raw_buffer_store_b128(v4, odesc, off, 0, 0);
+#endif
         };
 #pragma unroll
         for (int db = 0; db < DBLOCKS; ++db)
@@ -950,13 +958,15 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
             }
     };
     bool first_item = true;
-    for (int it_ = 0; PERSIST || it_ < 1; ++it_) {  // work items of this workgroup (exactly one unless PERSIST)
+    for (;;) {  // work items of this workgroup (exactly one unless PERSIST)
     if constexpr (PERSIST) {
+        FA_PSTAMP(59);  // loop top
         {
             int lane_i = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
             asm volatile("" : "+v"(lane_i));
             lane_tables(lane_i);
         }
+        FA_PSTAMP(60);  // lane tables rebuilt
         if (!first_item) {
             epilogue_persist();  // the previous item's O and LSE
             FA_PSTAMP(57);  // O stores issued

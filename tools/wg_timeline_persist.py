@@ -33,6 +33,9 @@ print("  -> generated block entry (first scores, softmax A(0))                 "
 print("  first block                                                           ", med(blk1 - blk0))
 print("  last block exit -> sweep closed (incl. masked block / generic tail)    ", med(a[:, :, 51] - np.maximum(a[:, :, 43], a[:, :, 45])))
 print("  -> O normalised, staged, stores issued                                ", med(a[:, :, 57] - a[:, :, 51]))
+if a[:, :, 58].min() > 0:
+    print("       sweep closed -> loop top ", med(a[:, :, 59] - a[:, :, 51]), "\n       -> lane tables      ", med(a[:, :, 60] - a[:, :, 59]),
+          "\n       -> LSE written      ", med(a[:, :, 58] - a[:, :, 60]), "\n       -> O stores issued  ", med(a[:, :, 57] - a[:, :, 58]))
 print("  -> item switch done (O zeroed, state reset)                           ", med(nx[:, :, 55] - a[:, :, 57]))
 print("  whole item                                                            ", med(nx[:, :, 55] - a[:, :, 55]))
 print("  last block exit of item i -> generated block entry of item i+1        ", med(np.where(nx[:, :, 42] > 0, nx[:, :, 42], nx[:, :, 44]) - np.maximum(a[:, :, 43], a[:, :, 45])))
