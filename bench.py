@@ -241,9 +241,33 @@ def spawn_ranks(args):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
-    rcs = [p.wait() for p in procs]
-    sys.stdout.write(out0.decode())
+    # rank 0's stdout is drained by a thread while every child is polled: a rank that dies before the rendezvous (bad device,
+    # import error) must not leave its siblings waiting in init_process_group until the store times out
+    import threading
+    import time
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    rcs = [None] * len(procs)
+    while any(rc is None for rc in rcs):
+        for i, p in enumerate(procs):
+            if rcs[i] is None:
+                rcs[i] = p.poll()
+        if any(rc not in (None, 0) for rc in rcs):
+            for i, p in enumerate(procs):  # first failure: end the siblings (exact PIDs this function started)
+                if rcs[i] is None:
+                    p.terminate()
+            for i, p in enumerate(procs):
+                if rcs[i] is None:
+                    try:
+                        rcs[i] = p.wait(timeout=10)
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                        rcs[i] = p.wait()
+            break
+        time.sleep(0.05)
+    reader.join(timeout=10)
+    sys.stdout.write(b"".join(c for c in chunks if c).decode())
     sys.stdout.flush()
     if any(rcs):
         print(f"bench.py: rank exit codes {rcs}", file=sys.stderr)
@@ -276,6 +300,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.dry_run and os.environ.get("FA_BENCH_DRY_FAIL_RANK") == str(rank):  # rehearsal of a rank lost before the rendezvous
+        sys.exit(3)
     if args.gpus != world:
         print(f"bench.py --gpus {args.gpus} was launched with WORLD_SIZE={world}", file=sys.stderr)
         sys.exit(2)
@@ -291,7 +317,9 @@ def main():
         device = torch.device("cuda", local_rank)
     dist = None
     if world > 1 or os.environ.get("FA_BENCH_FORCE_DIST"):  # (the env switch rehearses this path on one GPU)
+        import datetime
         import torch.distributed as dist
+        RENDEZVOUS_TIMEOUT = datetime.timedelta(seconds=int(os.environ.get("FA_BENCH_RENDEZVOUS_S", "180")))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # single node; the container hostname may not resolve
         # RCCL prints a version banner on stdout when it initialises: keep stdout for the one JSON line
@@ -300,10 +328,10 @@ def main():
         os.dup2(2, 1)
         try:
             if args.dry_run:
-                dist.init_process_group(backend="gloo")
+                dist.init_process_group(backend="gloo", timeout=RENDEZVOUS_TIMEOUT)
                 timing_group = dist.group.WORLD
             else:
-                dist.init_process_group(backend="nccl", device_id=device)
+                dist.init_process_group(backend="nccl", device_id=device, timeout=RENDEZVOUS_TIMEOUT)
                 dist.barrier()  # one collective over RCCL/xGMI: brings the communicator up outside the timed region
                 torch.cuda.synchronize()
                 # the timing bracket is a host-side barrier (gloo): attention shards over batch, there is no data-path

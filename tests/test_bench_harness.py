@@ -56,3 +56,16 @@ def test_strong_is_c5_only():
     r = subprocess.run([sys.executable, "bench.py", "--dry-run", "--scaling", "strong"], cwd=ROOT, env=_clean_env(),
                        capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "c5" in r.stderr
+
+
+def test_rank_lost_before_rendezvous_ends_the_launch():
+    """A rank that dies before init_process_group must not leave `bench.py --gpus N` hanging on the store timeout: the
+    parent polls every child, ends the siblings and exits non-zero (bench.py spawn_ranks)."""
+    import time
+    env = dict(_clean_env(), FA_BENCH_DRY_FAIL_RANK="1", FA_BENCH_RENDEZVOUS_S="120")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--dry-run", "--steps", "2"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=110)
+    assert r.returncode != 0 and "rank exit codes" in r.stderr
+    assert time.time() - t0 < 60  # well under the rendezvous timeout
+    assert not r.stdout.strip()
