@@ -5,7 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import flash_attention_annotated_amd as fa
 
-for d in (64, 96, 128):
+DIMS = tuple(int(x) for x in sys.argv[1].split(",")) if len(sys.argv) > 1 else (64, 96, 128, 160, 192, 256)
+for d in DIMS:
     for causal in (False, True):
         b, s = 2, 8192
         h = 2048 // d
