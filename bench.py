@@ -157,7 +157,7 @@ def check_rows(w, q, k, v, extra, result, n_rows=64):
     out = (result[0] if isinstance(result, (tuple, list)) else result).float().cpu()
     g = torch.Generator().manual_seed(1)
     fp8 = "fp8" in extra
-    worst, worst_bound = 0.0, 0.0
+    worst, worst_bound = None, None   # the sample that came closest to its bound
     seqs = [(i, 0, s) for i in range(b)] if lens is None else []
     if lens is not None:
         cu = extra["cu"].cpu().tolist()
@@ -187,7 +187,7 @@ def check_rows(w, q, k, v, extra, result, n_rows=64):
             atol = 1e-5
         err = (oi - ref.float()).abs().max().item()
         bound = 2 * (pt.float() - ref.float()).abs().max().item() + atol
-        if not (err <= bound) or err - bound > worst - worst_bound:
+        if worst is None or not (err <= bound) or err - bound > worst - worst_bound:
             worst, worst_bound = err, bound
         if not (err <= bound):
             return False, err, bound

@@ -27,7 +27,7 @@ def aligned(t):
 def launch(q, k, v, out, lse, *, varlen, batch, max_seqlen_q, max_seqlen_k, softmax_scale, causal, window_left,
            window_right, softcap, cu_seqlens_q=None, cu_seqlens_k=None, seqused_q=None, seqused_k=None,
            q_descale=None, k_descale=None, v_descale=None, alibi_slopes=None, kv_batch_idx=None, block_table=None, num_splits=1, leftpad_k=None,
-           p_dropout=0.0, rng_state=None, s_dmask=None, fa3_window=False, s_dmask_block_n=0):
+           p_dropout=0.0, rng_state=None, s_dmask=None, fa3_window=False, s_dmask_block_n=0, attention_chunk=0):
     """q/k/v/out: dense (b, s, h, d) or packed (total, h, d) tensors on one GPU, last stride 1, aligned()."""
     lib = _lib.load()
     prm = _lib.new_params()
@@ -76,6 +76,8 @@ def launch(q, k, v, out, lse, *, varlen, batch, max_seqlen_q, max_seqlen_k, soft
     if s_dmask is not None and s_dmask_block_n > 0:  # the reference's sign-encoded layout (b, h, rows, cols), input dtype
         prm.flags |= _lib.FA_FLAG_SDMASK_SIGNED
         prm.s_dmask_rows, prm.s_dmask_cols, prm.s_dmask_block_n = s_dmask.shape[-2], s_dmask.shape[-1], int(s_dmask_block_n)
+    prm.attention_chunk = int(attention_chunk)
+    prm.d_v = int(v.shape[-1]) if v.shape[-1] != q.shape[-1] else 0  # FA3 headdim_v (include/fa_fwd.h, ABI v12)
     prm.num_splits = int(num_splits)  # 1 = off (prefill entry points), 0 = library heuristic (decode), N = forced
     if block_table is not None:
         prm.block_table = ptr(block_table)

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, LIB_NAME)
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
-FA_ABI_VERSION = 11
+FA_ABI_VERSION = 12
 FA_FLAG_FA3_WINDOW = 1
 FA_FLAG_SDMASK_SIGNED = 2
 FA_DTYPE_FP16, FA_DTYPE_BF16, FA_DTYPE_FP8_E4M3 = 0, 1, 2
@@ -111,7 +111,9 @@ class FaFwdParams(ctypes.Structure):
         ("s_dmask_rows", ctypes.c_int32),
         ("s_dmask_cols", ctypes.c_int32),
         ("s_dmask_block_n", ctypes.c_int32),
-        ("reserved_sdmask", ctypes.c_int32),
+        ("attention_chunk", ctypes.c_int32),
+        ("d_v", ctypes.c_int32),
+        ("reserved_v12", ctypes.c_int32),
     ]
 
 

@@ -291,8 +291,13 @@ int block_m_of(int variant, int d);
 // workspace) for the shape BASELINE config 5 names -- head dim 128, dense or varlen, full / causal / right-window masks.  The
 // rest of the fp8 surface (other head dims, softcap, left windows) and an explicit kernel_variant take the exact
 // e4m3 -> bf16 expansion in front of the 16-bit kernels.
+// ABI v12: attention_chunk and a V head dim of its own exist in fwd_kernel only (the compiler-scheduled shape)
+inline bool own_dv(const fa_fwd_params *p) { return p->d_v > 0 && p->d_v != p->d; }
+inline bool generic_only(const fa_fwd_params *p) { return p->attention_chunk > 0 || own_dv(p); }
+inline int wide_dim(const fa_fwd_params *p) { return own_dv(p) ? std::max(p->d, std::min(p->d_v, 256)) : p->d; }  // what the LDS tile has to hold
+
 bool fp8_native(const fa_fwd_params *p) {
-    if (p->dtype != FA_DTYPE_FP8_E4M3 || p->d != 128) return false;
+    if (p->dtype != FA_DTYPE_FP8_E4M3 || p->d != 128 || generic_only(p)) return false;
     const int variant = p->kernel_variant ? p->kernel_variant : g_default_variant.load();
     if (variant != 0) return false;
     if (p->softcap > 0.f || p->alibi_slopes || p->block_table || p->kv_batch_idx || p->leftpad_k || p->p_dropout > 0.f) return false;
@@ -329,6 +334,7 @@ int effective_variant(const fa_fwd_params *p) {
     int variant = p->kernel_variant ? p->kernel_variant : g_default_variant.load();
     if (variant < 0 || variant > 3) variant = 0;
     if (p->p_dropout > 0.f) return 1;  // dropout lives in the compiler-scheduled shape only
+    if (generic_only(p)) return 1;  // fwd_kernel, EXTRA instantiations: 8 waves x 32 rows (4 x 32 at head-dim tile 256)
     if (variant == 0 || variant == 3) {
         if (p->block_table) variant = 1;
         else if (!p->cu_seqlens_q && p->seqlen_q <= 128) variant = 2;
@@ -359,10 +365,11 @@ SplitPlan split_plan(const fa_fwd_params *p, int variant) {
     SplitPlan sp{1, 0, 0, 0};
     if (p->cu_seqlens_q || p->dtype == FA_DTYPE_FP8_E4M3 || p->seqlen_q <= 0 || p->seqlen_k <= 0) return sp;
     if (p->p_dropout > 0.f) return sp;  // (the reference does not split under dropout either: flash_api.cpp:307)
+    if (own_dv(p)) return sp;           // (the partials and the merge are laid out for d columns)
     int n = p->num_splits;
     const int n_blocks = (p->seqlen_k + 63) / 64;
     if (n == 0) {
-        const int bm = block_m_of(variant, p->d);
+        const int bm = block_m_of(variant, wide_dim(p));
         const int64_t tiles = (int64_t)((p->seqlen_q + bm - 1) / bm) * p->h * p->b;
         // two workgroups of the 4-wave shape fit a CU: aim at ~4 per CU there, ~2 per CU for the 256-row kernel
         const int64_t cap = (variant == 2) ? 512 : 128, target = (variant == 2) ? 1024 : 512;
@@ -484,10 +491,10 @@ int head_dim_tile(int d) {
     return 256;
 }
 
-template <typename T, int D, int NWAVES, bool SOFTCAP, bool DROPOUT = false, int DEFF = D>
+template <typename T, int D, int NWAVES, bool SOFTCAP, bool DROPOUT = false, int DEFF = D, bool EXTRA = false>
 int launch(const fa::KParams &kp, hipStream_t stream) {
     constexpr int smem = fa::smem_bytes<D, NWAVES>();
-    auto kernel = fa::fwd_kernel<T, D, NWAVES, SOFTCAP, DROPOUT, DEFF>;
+    auto kernel = fa::fwd_kernel<T, D, NWAVES, SOFTCAP, DROPOUT, DEFF, EXTRA>;
     // the > 64 KiB dynamic-LDS opt-in is a per-device attribute of the kernel: one bit per device ordinal
     static std::atomic<uint64_t> attr_set{0};
     int dev = 0;
@@ -580,6 +587,13 @@ int dispatch_variant(const fa::KParams &kp, bool softcap, int variant, hipStream
     // variant 1  : 8 waves x 32 rows (BLOCK_M 256), two waves per SIMD (fa_fwd_kernel.h)
     // variant 2  : 4 waves x 32 rows (BLOCK_M 128)
     // D = 256 does not fit the w64 register budget (O alone would be 256 registers): 4 waves x 32 rows.
+    if (kp.chunk > 0 || kp.dv != kp.d) {
+        // attention_chunk / a V head dim of its own (FA3 surface, ABI v12): the EXTRA instantiations of the compiler-scheduled
+        // shape, 8 waves x 32 rows (4 at head-dim tile 256); no dropout on that surface (fa_fwd_validate)
+        constexpr int NW = D == 256 ? 4 : 8;
+        if (softcap) return launch<T, D, NW, true, false, D, true>(kp, stream);
+        return launch<T, D, NW, false, false, D, true>(kp, stream);
+    }
     if (kp.rp_dropout != 1.f) {  // dropout (p > 0, also when its 8-bit threshold keeps everything): its own instantiation of the compiler-scheduled shape (never with softcap)
         if constexpr (D == 256) return launch<T, D, 4, false, true>(kp, stream);
         else return launch<T, D, 8, false, true>(kp, stream);
@@ -618,7 +632,7 @@ int dispatch_variant(const fa::KParams &kp, bool softcap, int variant, hipStream
 
 template <typename T>
 int dispatch_hdim(const fa::KParams &kp, bool softcap, int variant, hipStream_t stream) {
-    switch (head_dim_tile(kp.d)) {
+    switch (head_dim_tile(std::max(kp.d, kp.dv))) {
         case 64: return dispatch_variant<T, 64>(kp, softcap, variant, stream);
         case 128: return dispatch_variant<T, 128>(kp, softcap, variant, stream);
         default: return dispatch_variant<T, 256>(kp, softcap, variant, stream);
@@ -788,6 +802,11 @@ int fa_fwd_validate(const fa_fwd_params *p) {
     if (p->d <= 0 || p->d > 256 || p->d % 8 != 0) return FA_ERR_BAD_HEAD_DIM;
     const bool fp8 = p->dtype == FA_DTYPE_FP8_E4M3;
     if (fp8 && p->d % 16 != 0) return FA_ERR_BAD_HEAD_DIM;  // hopper/flash_api.cpp:854-856
+    if (p->attention_chunk < 0) return FA_ERR_BAD_SHAPE;
+    if (p->d_v < 0 || p->d_v > 512 || p->d_v % 8 != 0) return FA_ERR_BAD_HEAD_DIM;  // 0 = d
+    if (own_dv(p) && (fp8 || p->block_table || p->num_splits > 1)) return FA_ERR_UNSUPPORTED;
+    if (generic_only(p) && p->p_dropout > 0.f) return FA_ERR_UNSUPPORTED;  // (no dropout on the FA3 surface)
+    if (p->attention_chunk > 0 && p->s_dmask) return FA_ERR_UNSUPPORTED;  // (the S_dmask pass knows windows only)
     if (p->h % p->h_k != 0) return FA_ERR_BAD_HEADS;
     if ((p->cu_seqlens_q == nullptr) != (p->cu_seqlens_k == nullptr)) return FA_ERR_BAD_SHAPE;
     if (p->cu_seqlens_q && p->total_q < 0) return FA_ERR_BAD_SHAPE;
@@ -856,8 +875,22 @@ int fa_fwd(const fa_fwd_params *p, void *stream_) {
     if (st != FA_OK) return st;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
 
+    if (p->d_v > 256) {
+        // V head dims above the widest tile (hopper/flash_api.cpp:783-792 allows up to 512 beside q/k <= 64): one launch per 256
+        // columns of V and O -- the scores are formed again for each (d <= 64: a small part of the work), the LSE is written
+        // by every launch with the same value.  Strides are untouched: the launches differ in the V / O column offset only.
+        for (int c = 0; c < p->d_v; c += 256) {
+            fa_fwd_params part = *p;
+            part.v = static_cast<const char *>(p->v) + (size_t)c * 2;
+            part.o = static_cast<char *>(p->o) + (size_t)c * 2;
+            part.d_v = std::min(256, p->d_v - c);
+            const int st_part = fa_fwd(&part, stream_);
+            if (st_part != FA_OK) return st_part;
+        }
+        return FA_OK;
+    }
     const int variant = effective_variant(p);
-    const int block_m = block_m_of(variant, p->d);
+    const int block_m = block_m_of(variant, wide_dim(p));
 
     fa::KParams kp{};
     kp.q = p->q; kp.k = p->k; kp.v = p->v; kp.o = p->o; kp.lse = p->softmax_lse;
@@ -903,6 +936,8 @@ int fa_fwd(const fa_fwd_params *p, void *stream_) {
     kp.o_batch_stride = p->o_batch_stride; kp.o_row_stride = p->o_row_stride; kp.o_head_stride = p->o_head_stride;
     kp.b = p->b; kp.seqlen_q = p->seqlen_q; kp.seqlen_k = p->seqlen_k; kp.h = p->h; kp.h_k = p->h_k; kp.d = p->d;
     kp.total_q = p->total_q;
+    kp.dv = own_dv(p) ? p->d_v : p->d;
+    kp.chunk = p->attention_chunk;
     kp.h_ratio = p->h / p->h_k;
     kp.num_m_blocks = (p->seqlen_q + block_m - 1) / block_m;
     const int64_t tiles = (int64_t)kp.num_m_blocks * p->h * p->b;

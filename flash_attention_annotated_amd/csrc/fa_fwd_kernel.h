@@ -79,7 +79,15 @@ struct KParams {
     uint8_t *s_dmask;
     int32_t drop_thr;
     float rp_dropout;
+    // ABI v12 (fwd_kernel only; the host keeps the pipelined kernels away from both): head dim of V / O (FA3 headdim_v,
+    // hopper/flash_api.cpp:764,782-792; = d everywhere else) and attention_chunk (hopper/mask.h:116-119; 0 = off)
+    int32_t dv;
+    int32_t chunk;
 };
+
+// floor(x / c) * c for c > 0 and any sign of x: first key of the attention chunk of diagonal position x (flash::round_down on
+// the reference's FastDivmod, hopper/mask.h:117; the oracle subtracts a Python remainder, hopper/test_util.py:220)
+__device__ __forceinline__ int chunk_floor(int x, int c) { return (x >= 0 ? x / c : -((-x + c - 1) / c)) * c; }
 
 // Counter-based random bytes for the dropout decision: ONE 32-bit avalanche (lowbias32) per 2 x 2 block of the score
 // matrix -- rows 2a, 2a+1 x keys 2b, 2b+1 of (batch*h + head) -- gives the four 8-bit values of the block (byte index
@@ -250,7 +258,9 @@ __device__ __forceinline__ float max3(float a, float b, float c) {
 // decode shape (D = 128, 4 waves, 256-register budget) a third of its speed in extra spills.
 // DEFF: head dims actually contracted / produced (<= D, multiple of 32): the k-steps and O blocks of the zero padding are
 // skipped while the LDS images keep the rows of the D tile (D = 256 with DEFF = 192: head dims 129..192, hopper/tile_size.h).
-template <typename T, int D, int NWAVES, bool SOFTCAP, bool DROPOUT = false, int DEFF = D>
+// EXTRA: the instantiations that know attention_chunk (p.chunk) and a V / O head dim of its own (p.dv) -- FA3-only arguments,
+// ABI v12.  Compiled out of the others: as run-time branches they cost the decode shape a spill inside its tile loop.
+template <typename T, int D, int NWAVES, bool SOFTCAP, bool DROPOUT = false, int DEFF = D, bool EXTRA = false>
 __global__ __launch_bounds__(NWAVES * 64, (D <= 128 ? 2 : 1)) void fwd_kernel(const KParams p) {
     constexpr int NT = NWAVES * 64;
     constexpr int BLOCK_M = NWAVES * 32;
@@ -337,6 +347,10 @@ __global__ __launch_bounds__(NWAVES * 64, (D <= 128 ? 2 : 1)) void fwd_kernel(co
     int key_hi = sk, key_lo = 0;
     if (p.window_right >= 0) key_hi = min(sk, row_hi + shift + p.window_right);
     if (p.window_left >= 0) key_lo = max(0, row_lo + shift - p.window_left);
+    if (EXTRA && p.chunk > 0) {  // attention_chunk: the block's rows see nothing outside [chunk start of its first row, chunk end of its last)
+        key_lo = max(key_lo, chunk_floor(row_lo + shift, p.chunk));
+        key_hi = min(key_hi, chunk_floor(row_hi - 1 + shift, p.chunk) + p.chunk);
+    }
     int n_min = key_lo / BLOCK_N;
     int n_max = key_hi > 0 ? (key_hi + BLOCK_N - 1) / BLOCK_N : 0;
     split_range(p, split, n_min, n_max);
@@ -390,6 +404,9 @@ __global__ __launch_bounds__(NWAVES * 64, (D <= 128 ? 2 : 1)) void fwd_kernel(co
     constexpr int ROWS_PER_PASS = NT / CH_PER_ROW;
     const int ld_row0 = tid / CH_PER_ROW;
     const int ld_col0 = ((tid % CH_PER_ROW) * 8 < p.d) ? (tid % CH_PER_ROW) * 8 : 0;
+    // V has p.dv columns (= p.d unless the FA3 headdim_v differs): chunks past them duplicate chunk 0 and only ever reach
+    // O columns >= dv, which the epilogue does not store
+    const int ld_col0v = !EXTRA ? ld_col0 : ((tid % CH_PER_ROW) * 8 < p.dv) ? (tid % CH_PER_ROW) * 8 : 0;
     const int k_rs = (int)p.k_row_stride, v_rs = (int)p.v_row_stride;  // host guarantees 64 * stride < 2^31
     auto load_tile = [&](int n) {
         const int k0 = n * BLOCK_N;
@@ -409,7 +426,7 @@ __global__ __launch_bounds__(NWAVES * 64, (D <= 128 ? 2 : 1)) void fwd_kernel(co
                     const int64_t page = pages[pi];
                     const int in_page = row - pi * p.page_size;
                     kreg[i] = *(const u32x4 *)(kp + page * p.k_batch_stride + (int64_t)in_page * p.k_row_stride + ld_col0);
-                    vreg[i] = *(const u32x4 *)(vp + page * p.v_batch_stride + (int64_t)in_page * p.v_row_stride + ld_col0);
+                    vreg[i] = *(const u32x4 *)(vp + page * p.v_batch_stride + (int64_t)in_page * p.v_row_stride + ld_col0v);
                 }
                 return;
             }
@@ -418,7 +435,7 @@ __global__ __launch_bounds__(NWAVES * 64, (D <= 128 ? 2 : 1)) void fwd_kernel(co
         for (int i = 0; i < LD_PER_THREAD; ++i) {
             const int row = min(ld_row0 + i * ROWS_PER_PASS, last);
             kreg[i] = *(const u32x4 *)(kt + (uint32_t)(row * k_rs + ld_col0));
-            vreg[i] = *(const u32x4 *)(vt + (uint32_t)(row * v_rs + ld_col0));
+            vreg[i] = *(const u32x4 *)(vt + (uint32_t)(row * v_rs + ld_col0v));
         }
     };
     auto store_tile = [&](int buf) {
@@ -465,6 +482,11 @@ __global__ __launch_bounds__(NWAVES * 64, (D <= 128 ? 2 : 1)) void fwd_kernel(co
         if (p.window_left >= 0) {
             skip = skip || (k0 + BLOCK_N - 1 < wrow + shift - p.window_left);
             need_mask = need_mask || (k0 < wrow + 31 + shift - p.window_left);
+        }
+        if (EXTRA && p.chunk > 0) {  // the wave's rows see [w_lo, w_hi) at most; all of them see [w_in_lo, w_in_hi) (may be empty)
+            const int w_lo = chunk_floor(wrow + shift, p.chunk), w_in_lo = chunk_floor(wrow + 31 + shift, p.chunk);
+            skip = skip || (k0 + BLOCK_N - 1 < w_lo) || (k0 >= w_in_lo + p.chunk);
+            need_mask = need_mask || (k0 < w_in_lo) || (k0 + BLOCK_N > w_lo + p.chunk);
         }
 
         if (!skip) {
@@ -514,6 +536,11 @@ __global__ __launch_bounds__(NWAVES * 64, (D <= 128 ? 2 : 1)) void fwd_kernel(co
                 int lim_lo = 0;   // inclusive
                 if (p.window_right >= 0) lim_hi = min(sk, my_row + shift + p.window_right + 1);
                 if (p.window_left >= 0) lim_lo = max(0, my_row + shift - p.window_left);
+                if (EXTRA && p.chunk > 0) {  // hopper/mask.h:116-119: the window intersected with the row's chunk
+                    const int c_lo = chunk_floor(my_row + shift, p.chunk);
+                    lim_lo = max(lim_lo, c_lo);
+                    lim_hi = min(lim_hi, c_lo + p.chunk);
+                }
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -623,7 +650,7 @@ __global__ __launch_bounds__(NWAVES * 64, (D <= 128 ? 2 : 1)) void fwd_kernel(co
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) {
                         const int col = db * 32 + 8 * g4 + 4 * hh;
-                        if (col < p.d)
+                        if (col < (EXTRA ? p.dv : p.d))
                             *(float4 *)(opf + col) = make_float4(o_acc[db][4 * g4] * inv, o_acc[db][4 * g4 + 1] * inv,
                                                                  o_acc[db][4 * g4 + 2] * inv, o_acc[db][4 * g4 + 3] * inv);
                     }
@@ -658,7 +685,7 @@ __global__ __launch_bounds__(NWAVES * 64, (D <= 128 ? 2 : 1)) void fwd_kernel(co
         for (int i = 0; i < NCH; ++i) {
             const int c = lane + i * 64;
             const int row = c / CH_PER_ROW, ch = c % CH_PER_ROW;
-            if (wrow + row < sq && ch * 8 < p.d) *(u32x4 *)(op + (int64_t)(wrow + row) * p.o_row_stride + ch * 8) = val[i];
+            if (wrow + row < sq && ch * 8 < (EXTRA ? p.dv : p.d)) *(u32x4 *)(op + (int64_t)(wrow + row) * p.o_row_stride + ch * 8) = val[i];
         }
     }
 }

@@ -40,13 +40,23 @@ def fwd(q, k, v, k_new, v_new, qv, out, cu_seqlens_q, cu_seqlens_k, cu_seqlens_k
         _check(t.stride(-1) == 1, "Input tensor must have contiguous last dimension")
     for x, n in ((qv, "qv"), (seqlens_rotary, "seqlens_rotary"), (cu_seqlens_k_new, "cu_seqlens_k_new")):
         _check(x is None, f"This flash attention build does not support {n}.")
-    _check(not attention_chunk, "This flash attention build does not support attention_chunk.")
+    attention_chunk = int(attention_chunk or 0)
+    _check(attention_chunk >= 0, "attention_chunk must be non-negative")
     is_fp8 = _FP8 is not None and q.dtype == _FP8
+    head_size_v = v.shape[-1]  # hopper/flash_api.cpp:764
+    if head_size_v != q.shape[-1]:  # :782-792 (the "Only Hopper" line is the one check that does not carry over)
+        _check((128 < q.shape[-1] <= 192 and 96 < head_size_v <= 128) or (q.shape[-1] <= 64 and head_size_v <= 512),
+               "If V headdim is different from Q/K dim, we only support Q/K headdim in (128, 192] and V headdim in (96, 128], "
+               "or (Q/K <= 64 and V <= 512).")
+        _check(not is_fp8, "This flash attention build does not support a V headdim of its own with fp8 inputs.")
+        _check(head_size_v % 8 == 0, "head_size_v should be a multiple of 8")  # :856
     if any(x is not None for x in (k_new, v_new, page_table, kv_batch_idx, leftpad_k, rotary_cos, rotary_sin)):
         # KV-cache step (hopper/flash_api.cpp:736-760, 935-1060): k / v are the cache, seqused_k its fill levels
         _check(cu_seqlens_q is None and cu_seqlens_k is None and seqused_q is None,
                "This flash attention build does not support KV-cache arguments together with cu_seqlens / seqused_q.")
         _check(not is_fp8, "This flash attention build does not support KV-cache arguments with fp8 inputs.")
+        _check(not attention_chunk and head_size_v == q.shape[-1],
+               "This flash attention build does not support attention_chunk or a V headdim of its own with KV-cache arguments.")
         _check((k_new is None) == (v_new is None), "k_new and v_new must be passed together")
         _check((rotary_cos is None) == (rotary_sin is None), "rotary_cos and rotary_sin must be passed together")
         if k_new is not None or leftpad_k is not None:
@@ -61,7 +71,7 @@ def fwd(q, k, v, k_new, v_new, qv, out, cu_seqlens_q, cu_seqlens_k, cu_seqlens_k
         return o, lse, None, None
     if (cu_seqlens_q is None and cu_seqlens_k is None and seqused_q is None and seqused_k is not None and not is_fp8
             and q.dim() == 4 and q.shape[1] <= 128 and window_size_left < 0 and (window_size_right < 0 or is_causal)
-            and out is None):
+            and out is None and not attention_chunk and head_size_v == q.shape[-1]):
         # plain decode over a cache (flash_attn_with_kvcache(q, k_cache, v_cache, cache_seqlens=...)): the same routine as
         # the append / paged calls, which brings the split-KV heuristic (num_splits = 0) and the (b, 1, h) -> (b, ngroups, h_k)
         # GQA swap (hopper/flash_api.cpp:935-1060 runs them for every call with seqused_k)
@@ -88,6 +98,9 @@ def fwd(q, k, v, k_new, v_new, qv, out, cu_seqlens_q, cu_seqlens_k, cu_seqlens_k
         seqlen_k, num_heads_k = k.shape[1], k.shape[2]
         total_q = batch_size * seqlen_q
     _check(batch_size > 0, "batch size must be positive")
+    # CHECK_SHAPE(k, ..., num_heads_k, head_size) / CHECK_SHAPE(v, ..., num_heads_k, head_size_v), hopper/flash_api.cpp:813-819
+    _check(k.shape[-1] == head_size, f"k must have shape (..., {num_heads_k}, {head_size})")
+    _check(tuple(v.shape[:-1]) == tuple(k.shape[:-1]), f"v must have shape {tuple(k.shape[:-1]) + (head_size_v,)}")
     _check(head_size <= 256, "FlashAttention forward only supports head dimension at most 256")
     _check(head_size % (16 if is_fp8 else 8) == 0,
            f"head_size should be a multiple of {16 if is_fp8 else 8}")  # :854-856
@@ -106,16 +119,17 @@ def fwd(q, k, v, k_new, v_new, qv, out, cu_seqlens_q, cu_seqlens_k, cu_seqlens_k
         window_size_left = -1
     if window_size_right >= seqlen_q - 1:
         window_size_right = -1
-    if seqlen_q == 1 and window_size_left == -1 and window_size_right == -1:
+    if seqlen_q == 1 and window_size_left == -1 and window_size_right == -1 and attention_chunk == 0:
         is_causal = False  # causal=true is the same as causal=false in this case
     if is_causal:
         window_size_right = 0
     out_dtype = torch.bfloat16 if is_fp8 else q.dtype  # :859
     if out is not None:
         _check(out.dtype == out_dtype, "For FP8 input, output must have dtype BF16" if is_fp8 else "Output must have the same dtype as inputs")
-        _check(out.is_cuda and out.stride(-1) == 1 and tuple(out.shape) == tuple(q.shape), "out must match q")
+        _check(out.is_cuda and out.stride(-1) == 1 and tuple(out.shape) == tuple(q.shape[:-1]) + (head_size_v,),
+               "out must have shape (..., num_heads, head_size_v)")  # :866-870
     else:
-        out = torch.empty(q.shape, dtype=out_dtype, device=q.device)
+        out = torch.empty(tuple(q.shape[:-1]) + (head_size_v,), dtype=out_dtype, device=q.device)  # :872-874
     with torch.cuda.device(q.device):
         lse_shape = (num_heads, total_q) if varlen_q else (batch_size, num_heads, seqlen_q)
         softmax_lse = torch.empty(lse_shape, dtype=torch.float32, device=q.device)
@@ -127,6 +141,7 @@ def fwd(q, k, v, k_new, v_new, qv, out, cu_seqlens_q, cu_seqlens_k, cu_seqlens_k
                              window_left=window_size_left, window_right=window_size_right, softcap=softcap,
                              cu_seqlens_q=cu_seqlens_q, cu_seqlens_k=cu_seqlens_k, seqused_q=seqused_q,
                              seqused_k=seqused_k, q_descale=q_descale, k_descale=k_descale, v_descale=v_descale,
+                             attention_chunk=attention_chunk,
                              fa3_window=True)  # a missing window side is unbounded (hopper/flash_api.cpp:152-153)
             if oc is not out:
                 out.copy_(oc)

@@ -60,6 +60,8 @@ def _bwd(dout, q, k, v, out, softmax_lse, dq=None, dk=None, dv=None, cu_seqlens_
     """mha_bwd, hopper/flash_api.cpp:1259-1570, on the FA2-shaped backward of this build (16-bit types)."""
     if seqused_q is not None or seqused_k is not None:
         raise RuntimeError("This flash attention build does not support seqused_q / seqused_k in the backward.")
+    if v.shape[-1] != q.shape[-1]:  # (the reference's backward takes it, hopper/flash_api.cpp:1345-1369)
+        raise RuntimeError("This flash attention build does not support a V headdim different from the Q/K headdim in the backward.")
     if softmax_scale is None:
         softmax_scale = q.shape[-1] ** (-0.5)
     # window normalisation of the FA3 entry points (hopper/flash_api.cpp:1360-1361, as :796-797 of the forward): a side that

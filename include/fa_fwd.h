@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define FA_ABI_VERSION 11
+#define FA_ABI_VERSION 12
 
 #define FA_FLAG_FA3_WINDOW 1
 #define FA_FLAG_SDMASK_SIGNED 2   /* s_dmask is the reference's sign-encoded probability tensor (below), not random bytes */
@@ -189,7 +189,17 @@ typedef struct fa_fwd_params {
      * NEGATIVE sign where dropout discards the element.  s_dmask_block_n = the reference's kBlockN for this head dim
      * (flash_attn/flash_attn_interface.py:23-46).  Testing aid like the reference's: written by a pass of its own behind the
      * forward (fa_sdmask in fa_fwd_api.hip), seqlen_k <= 32768. */
-    int32_t s_dmask_rows, s_dmask_cols, s_dmask_block_n, reserved_sdmask;
+    int32_t s_dmask_rows, s_dmask_cols, s_dmask_block_n;
+    /* ABI v12 -- attention_chunk (FA3, hopper/flash_api.cpp:148-160, hopper/mask.h:116-119, hopper/block.h:30-42; oracle
+     * construct_chunk_mask hopper/test_util.py:193-223): C > 0 = query i only sees the keys of its own chunk,
+     * [floor((i + seqlen_k - seqlen_q) / C) * C, ... + C), intersected with the causal / window mask.  0 = off.  Forward only
+     * (the reference's backward has no such argument, hopper/flash_api.cpp:1523), 16-bit and expanded-fp8 kernels. */
+    int32_t attention_chunk;
+    /* ABI v12 -- head dim of V and O when it differs from d (FA3 "headdim_v", hopper/flash_api.cpp:764,782-792: q/k in
+     * (128, 192] with v in (96, 128], or q/k <= 64 with v <= 512): v is (.., h_k, d_v), o (.., h, d_v).  0 = d.  Multiple of 8,
+     * <= 512; above 256 the library runs one launch per 256 columns of V.  16-bit types; not with split-KV, paged or fp8. */
+    int32_t d_v;
+    int32_t reserved_v12;
 } fa_fwd_params;
 
 /* Validate and enqueue the forward on `stream` (a hipStream_t; NULL = default

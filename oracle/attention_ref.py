@@ -38,6 +38,24 @@ def local_mask(seqlen_q, seqlen_k, window_size=(-1, -1), query_padding_mask=None
     return torch.logical_or(j > torch.minimum(diag + right, sk_t), j < diag - left)
 
 
+def chunk_mask(seqlen_q, seqlen_k, attention_chunk, query_padding_mask=None, key_padding_mask=None, device=None,
+               key_leftpad=None):
+    """True where key j lies outside the attention chunk of query i (FA3 `attention_chunk`, construct_chunk_mask
+    hopper/test_util.py:193-223): visible iff  c <= j < c + chunk  with  c = (i + sk - sq) - (i + sk - sq) % chunk  (floor
+    remainder, so rows whose diagonal position is negative see a chunk that ends at or before key 0: nothing)."""
+    i = torch.arange(seqlen_q, device=device, dtype=torch.long).view(-1, 1)
+    j = torch.arange(seqlen_k, device=device, dtype=torch.long).view(1, -1)
+    if key_leftpad is not None:
+        lp = key_leftpad.long().view(-1, 1, 1, 1)
+        j = j.view(1, 1, 1, -1).expand(lp.shape[0], 1, 1, seqlen_k)
+        j = torch.where(j >= lp, j - lp, 2 ** 32)
+    sk = seqlen_k if key_padding_mask is None else key_padding_mask.sum(-1).view(-1, 1, 1, 1)
+    sq = seqlen_q if query_padding_mask is None else query_padding_mask.sum(-1).view(-1, 1, 1, 1)
+    diag = i + sk - sq
+    lo = diag - torch.remainder(diag, attention_chunk)
+    return torch.logical_or(j < lo, j >= lo + attention_chunk)
+
+
 def attn_bias_from_alibi_slopes(slopes, seqlen_q, seqlen_k, query_padding_mask=None, key_padding_mask=None,
                                 causal=False, key_leftpad=None):
     """ALiBi bias (b, h, sq|1, sk) from fp32 slopes (b, h): tests/test_flash_attn.py:29-56.
@@ -86,10 +104,13 @@ def apply_rotary_emb_ref(x, cos, sin, seqlen_offsets, interleaved=False, per_row
 
 def attention_ref(q, k, v, query_padding_mask=None, key_padding_mask=None, attn_bias=None, causal=False,
                   window_size=(-1, -1), softcap=0.0, upcast=True, reorder_ops=False, return_lse=False,
-                  q_descale=None, k_descale=None, v_descale=None, intermediate_dtype=None, key_leftpad=None, dropout_p=0.0, dropout_mask=None):
+                  q_descale=None, k_descale=None, v_descale=None, intermediate_dtype=None, key_leftpad=None, dropout_p=0.0, dropout_mask=None,
+                  attention_chunk=0):
     """Exact softmax attention.
 
-    q: (b, sq, h, d); k, v: (b, sk, h_k, d) with h % h_k == 0 (kv head = q head // (h/h_k)).
+    q: (b, sq, h, d); k: (b, sk, h_k, d), v: (b, sk, h_k, dv) with h % h_k == 0 (kv head = q head // (h/h_k)); dv may differ
+    from d (FA3 headdim_v, hopper/test_util.py:245-246): out is (b, sq, h, dv).  attention_chunk > 0: chunk_mask() on top of the
+    window mask (hopper/test_util.py:310-320).
     upcast=True  -> everything in fp32 ("out_ref" of the reference's tests);
     upcast=False, reorder_ops=True -> same math in the input precision with k scaled instead of q
     ("out_pt", the yardstick of the tolerance contract, tests/test_flash_attn.py:1121).
@@ -125,6 +146,10 @@ def attention_ref(q, k, v, query_padding_mask=None, key_padding_mask=None, attn_
     masked = None
     if window_size[0] >= 0 or window_size[1] >= 0:
         masked = local_mask(sq, sk, window_size, query_padding_mask, key_padding_mask, q.device, key_leftpad)
+    if attention_chunk > 0:
+        cm = chunk_mask(sq, sk, attention_chunk, query_padding_mask, key_padding_mask, q.device, key_leftpad)
+        masked = cm if masked is None else torch.logical_or(masked, cm)
+    if masked is not None:
         scores = scores.masked_fill(masked, float("-inf"))
     if attn_bias is not None:
         scores = scores + attn_bias

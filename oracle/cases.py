@@ -58,6 +58,32 @@ CASES = {
 }
 
 
+def _fa3_case(dtype, b, sq, sk, h, hk, d, dv=0, chunk=0, **kw):
+    c = _case(dtype, b, sq, sk, h, hk, d, **kw)
+    c["dv"], c["chunk"] = (dv or d), chunk
+    return c
+
+
+# FA3-only forward arguments (the `dv` / `attention_chunk` axes of hopper/test_flash_attn.py:120-131): pinned to the FA3
+# oracle hopper/test_util.py:226-348 (construct_chunk_mask :193-223), frozen in tests/golden/attention_fa3_golden.pt.
+FA3_CASES = {
+    "fa3_chunk100_gqa_d64": _fa3_case("bf16", 2, 256, 256, 4, 2, 64, chunk=100, seed=60),
+    "fa3_chunk37_causal_113_203": _fa3_case("bf16", 2, 113, 203, 4, 4, 64, chunk=37, causal=True, seed=61),
+    "fa3_chunk64_local_40_10_d128": _fa3_case("fp16", 1, 200, 200, 2, 2, 128, chunk=64, window=(40, 10), seed=62),
+    "fa3_chunk50_causal_sq_gt_sk": _fa3_case("bf16", 1, 300, 128, 2, 1, 64, chunk=50, causal=True, seed=63),
+    "fa3_chunk500_no_effect": _fa3_case("bf16", 1, 128, 160, 2, 2, 64, chunk=500, seed=64),
+    "fa3_chunk1": _fa3_case("bf16", 1, 70, 90, 2, 2, 64, chunk=1, seed=65),
+    "fa3_chunk48_padded": _fa3_case("bf16", 3, 128, 217, 4, 2, 64, chunk=48, padding="random", seed=66),
+    "fa3_chunk96_d256_causal": _fa3_case("bf16", 1, 260, 300, 2, 1, 256, chunk=96, causal=True, seed=67),
+    "fa3_dv128_d192_gqa_causal": _fa3_case("bf16", 2, 130, 190, 4, 2, 192, dv=128, causal=True, seed=68),
+    "fa3_dv128_d160": _fa3_case("fp16", 1, 150, 150, 2, 2, 160, dv=128, seed=69),
+    "fa3_dv256_d64": _fa3_case("bf16", 1, 140, 200, 2, 1, 64, dv=256, seed=70),
+    "fa3_dv512_d64_local": _fa3_case("bf16", 1, 128, 128, 2, 2, 64, dv=512, window=(50, 20), seed=71),
+    "fa3_dv320_d32": _fa3_case("bf16", 1, 65, 100, 2, 2, 32, dv=320, causal=True, seed=72),
+    "fa3_dv128_d192_chunk80_padded": _fa3_case("bf16", 2, 160, 160, 4, 2, 192, dv=128, chunk=80, padding="random", seed=73),
+}
+
+
 # Backward fixtures: small problems whose dq/dk/dv (reference oracle + autograd, the way tests/test_flash_attn.py:1071-1105
 # obtains dq_ref / dq_pt) are frozen in tests/golden/attention_grad_golden.pt.  Stored in full (store_row_stride = 1).
 GRAD_CASES = {
@@ -84,7 +110,7 @@ def make_inputs(c):
     dt = _DT[c["dtype"]]
     q = torch.randn(c["b"], c["sq"], c["h"], c["d"], generator=g, dtype=torch.float32)
     k = torch.randn(c["b"], c["sk"], c["hk"], c["d"], generator=g, dtype=torch.float32)
-    v = torch.randn(c["b"], c["sk"], c["hk"], c["d"], generator=g, dtype=torch.float32)
+    v = torch.randn(c["b"], c["sk"], c["hk"], c.get("dv", c["d"]), generator=g, dtype=torch.float32)
     q = q * c["q_scale"]
     q, k, v = q.to(dt), k.to(dt), v.to(dt)
     if c.get("fp8"):  # values an e4m3 tensor can hold, kept in bf16 for the oracle (the kernel gets .to(float8_e4m3fn))

@@ -23,7 +23,7 @@ REF = "/root/reference"
 sys.path.insert(0, ROOT)
 
 from oracle import attention_ref as mine  # noqa: E402
-from oracle.cases import CASES, GRAD_CASES, make_grad_output, make_alibi_slopes, make_descales, make_inputs, padding_masks, checksum  # noqa: E402
+from oracle.cases import CASES, FA3_CASES, GRAD_CASES, make_grad_output, make_alibi_slopes, make_descales, make_inputs, padding_masks, checksum  # noqa: E402
 
 
 def import_reference():
@@ -158,6 +158,41 @@ def main():
     out_path = os.path.join(ROOT, "tests/golden/attention_ref_golden.pt")
     torch.save(golden, out_path)
     print(f"wrote {out_path} ({os.path.getsize(out_path) / 1e6:.2f} MB), worst fp32 deviation {worst:.2e}")
+
+    # ---- FA3-only forward arguments: attention_chunk (construct_chunk_mask hopper/test_util.py:193-223) and a V head dim of
+    #      its own (:245-246, :284-285), pinned to the FA3 oracle called the way hopper/test_flash_attn.py:163-181 does ----
+    fa3_golden = {}
+    for name, c in FA3_CASES.items():
+        q, k, v = make_inputs(c)
+        qm, km = padding_masks(c)
+        kw = dict(causal=c["causal"], window_size=c["window"], softcap=c["softcap"], attention_chunk=c["chunk"])
+        ref_out, ref_attn = fa3.attention_ref(q, k, v, qm, km, **kw)
+        ref_pt, _ = fa3.attention_ref(q, k, v, qm, km, **kw, upcast=False, reorder_ops=True)
+        ref_out32, _ = fa3.attention_ref(q.float(), k.float(), v.float(), qm, km, **kw)
+        my_out, my_attn, my_lse = mine.attention_ref(q, k, v, qm, km, **kw, return_lse=True)
+        my_pt, _ = mine.attention_ref(q, k, v, qm, km, **kw, upcast=False, reorder_ops=True)
+        my_out32, _ = mine.attention_ref(q.float(), k.float(), v.float(), qm, km, **kw)
+        assert tuple(ref_out.shape) == (c["b"], c["sq"], c["h"], c["dv"]), name
+        e1 = (my_out32 - ref_out32).abs().max().item()
+        e2 = (my_pt.float() - ref_pt.float()).abs().max().item()
+        e4 = (my_attn.float() - ref_attn.float()).abs().max().item()
+        # (q * scale there, q / sqrt(d) here: fp32 rounding noise; in 16 bits the two roundings of q differ by an ulp)
+        assert e1 <= 5e-6 and e2 <= 1.6e-2 and e4 <= 4e-3, (name, e1, e2, e4)
+        if c["chunk"] > 0:  # the mask itself, bit for bit
+            want = fa3.construct_chunk_mask(c["sq"], c["sk"], c["chunk"], qm, km)
+            assert torch.equal(want, mine.chunk_mask(c["sq"], c["sk"], c["chunk"], qm, km)), (name, "chunk mask")
+        stride = c.get("store_row_stride", 1)
+        fa3_golden[name] = {
+            "case": {k2: (list(v2) if isinstance(v2, tuple) else v2) for k2, v2 in c.items()},
+            "input_checksum": torch.tensor([checksum(q), checksum(k), checksum(v)], dtype=torch.float64),
+            "out_ref_fp32": ref_out32[:, ::stride].contiguous(),
+            "out_pt": ref_pt[:, ::stride].contiguous(),
+            "lse": my_lse[:, :, ::stride].contiguous(),
+        }
+        print(f"{name:34s} fp32 err {e1:.2e}  pt err {e2:.1e}  probs {e4:.1e}  (FA3 oracle: chunk {c['chunk']}, dv {c['dv']})")
+    out_path = os.path.join(ROOT, "tests/golden/attention_fa3_golden.pt")
+    torch.save(fa3_golden, out_path)
+    print(f"wrote {out_path} ({os.path.getsize(out_path) / 1e6:.2f} MB)")
 
     # ---- left-padded keys (key_leftpad of tests/test_util.py:150-182 and tests/test_flash_attn.py:29-56): restatement
     #      == reference, mask and ALiBi bias

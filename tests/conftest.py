@@ -39,6 +39,14 @@ def golden():
 
 
 @pytest.fixture(scope="session")
+def golden_fa3():
+    """Outputs of the reference's FA3 oracle (hopper/test_util.py:226-348) for the `attention_chunk` / `dv` cases of
+    oracle/cases.py:FA3_CASES, frozen by oracle/make_golden.py (tensors only)."""
+    import torch
+    return torch.load(os.path.join(ROOT, "tests", "golden", "attention_fa3_golden.pt"), weights_only=True)
+
+
+@pytest.fixture(scope="session")
 def built_lib():
     """Build (if stale) and load the C-ABI library.  hipcc cross-compiles without a GPU."""
     import torch

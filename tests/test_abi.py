@@ -66,6 +66,11 @@ def test_validate_accepts_good_params(built_lib):
     (lambda p: setattr(p, "k", 0x10008), -6),               # base not 16-byte aligned
     (lambda p: setattr(p, "abi_version", 99), -9),          # FA_ERR_BAD_ABI
     (lambda p: setattr(p, "struct_size", 8), -9),
+    (lambda p: setattr(p, "attention_chunk", -1), -5),      # ABI v12
+    (lambda p: setattr(p, "d_v", 520), -3),                 # V head dim > 512
+    (lambda p: setattr(p, "d_v", 100), -3),                 # V head dim % 8
+    (lambda p: (setattr(p, "d_v", 128), setattr(p, "dtype", 2), setattr(p, "d", 64)), -7),   # own V head dim: 16-bit types only
+    (lambda p: (setattr(p, "d_v", 128), setattr(p, "num_splits", 4)), -7),                   # ... and no split-KV
 ])
 def test_validate_rejects(built_lib, mutate, code):
     p = _good()
@@ -75,6 +80,15 @@ def test_validate_rejects(built_lib, mutate, code):
     assert len(built_lib.fa_strerror(st)) > 0
     # fa_fwd runs the same validation before touching the device: same code, nothing launched
     assert built_lib.fa_fwd(ctypes.byref(p), None) == code
+
+
+def test_v12_fields_accepted(built_lib):
+    """attention_chunk and d_v (include/fa_fwd.h, ABI v12): valid combinations pass validation and need no workspace."""
+    for chunk, dv in ((64, 0), (0, 128), (0, 512), (7, 256), (0, 64)):
+        p = _good()
+        p.attention_chunk, p.d_v, p.num_splits = chunk, dv, 1
+        assert built_lib.fa_fwd_validate(ctypes.byref(p)) == 0, (chunk, dv)
+        assert built_lib.fa_fwd_workspace_size(ctypes.byref(p)) == 0
 
 
 def test_error_texts_are_the_reference_messages(built_lib):

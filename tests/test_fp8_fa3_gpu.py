@@ -155,8 +155,6 @@ def test_fa3_rejections():
     q = torch.randn(1, 16, 2, 64, dtype=torch.bfloat16, device=DEV)
     with pytest.raises(RuntimeError, match="does not support qv"):
         fa3.flash_attn_func(q, q, q, qv=q)
-    with pytest.raises(RuntimeError, match="attention_chunk"):
-        fa3.flash_attn_func(q, q, q, attention_chunk=8)
     q8 = torch.randn(1, 16, 2, 72, dtype=torch.bfloat16, device=DEV).to(FP8)
     with pytest.raises(RuntimeError, match="multiple of 16"):
         fa3.flash_attn_func(q8, q8, q8)

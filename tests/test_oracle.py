@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from oracle import attention_ref as oracle
-from oracle.cases import CASES, checksum, make_alibi_slopes, make_descales, make_inputs, padding_masks
+from oracle.cases import CASES, FA3_CASES, checksum, make_alibi_slopes, make_descales, make_inputs, padding_masks
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -43,6 +43,42 @@ def test_oracle_reproduces_reference_golden(name, golden):
     assert torch.equal(torch.isfinite(lse[:, :, ::st]), fin)
     if fin.any():
         assert (lse[:, :, ::st][fin] - g["lse"][fin]).abs().max().item() <= 1e-5
+
+
+@pytest.mark.parametrize("name", list(FA3_CASES))
+def test_oracle_reproduces_fa3_golden(name, golden_fa3):
+    """tests/golden/attention_fa3_golden.pt: the reference's FA3 oracle (hopper/test_util.py:226-348) on the attention_chunk /
+    head-dim-of-V cases (the `dv` and `attention_chunk` axes of hopper/test_flash_attn.py:120-131)."""
+    c, g = FA3_CASES[name], golden_fa3[name]
+    q, k, v = make_inputs(c)
+    assert v.shape[-1] == c["dv"]
+    for t, want in zip((q, k, v), g["input_checksum"].tolist()):
+        assert abs(checksum(t) - want) <= 1e-6 * max(1.0, abs(want)), "seeded inputs differ from the frozen ones"
+    qm, km = padding_masks(c)
+    kw = dict(causal=c["causal"], window_size=tuple(c["window"]), softcap=c["softcap"], attention_chunk=c["chunk"])
+    st = c["store_row_stride"]
+    out32, _ = oracle.attention_ref(q.float(), k.float(), v.float(), qm, km, **kw)
+    out_pt, _ = oracle.attention_ref(q, k, v, qm, km, **kw, upcast=False, reorder_ops=True)
+    assert out32.shape[-1] == c["dv"]
+    assert (out32[:, ::st] - g["out_ref_fp32"]).abs().max().item() <= 5e-6
+    assert (out_pt[:, ::st].float() - g["out_pt"].float()).abs().max().item() <= 2e-2 + 1e-6
+    _, _, lse = oracle.attention_ref(q, k, v, qm, km, **kw, return_lse=True)
+    fin = torch.isfinite(g["lse"])
+    assert torch.equal(torch.isfinite(lse[:, :, ::st]), fin)
+    if fin.any():
+        assert (lse[:, :, ::st][fin] - g["lse"][fin]).abs().max().item() <= 1e-5
+
+
+def test_chunk_mask_by_definition():
+    """construct_chunk_mask (hopper/test_util.py:193-223) against the definition spelled out per element, incl. rows whose
+    diagonal position is negative (seqlen_q > seqlen_k: Python floor remainder -> the chunk ends at or before key 0)."""
+    for sq, sk, chunk in ((7, 10, 3), (10, 4, 4), (5, 5, 1), (6, 9, 20)):
+        m = oracle.chunk_mask(sq, sk, chunk)
+        for i in range(sq):
+            diag = i + sk - sq
+            lo = (diag // chunk) * chunk
+            for j in range(sk):
+                assert bool(m[i, j]) == (not (lo <= j < lo + chunk)), (sq, sk, chunk, i, j)
 
 
 def _c_oracle():
