@@ -87,6 +87,22 @@ int run_bwd(fa::BParams bp, int rows_q_max, int rows_k_max, hipStream_t stream) 
                 static std::atomic<uint64_t> attr96{0};
                 st = bp.d <= 96 ? launch_kernel(fa::bwd_dkdv_kernel<T, D, 1, false, false, 96>, fa::smem_bytes_dkdv<D>(), attr96, bp.grid, 256, bp, stream)
                                 : launch_kernel(fa::bwd_dkdv_kernel<T, D, 1, false, false>, fa::smem_bytes_dkdv<D>(), attr, bp.grid, 256, bp, stream);
+            } else if constexpr (D == 256) {
+                // head-dim tile 256: dV and dK by a launch each (PART 1 / 2, fa_bwd_kernel.h) -- one accumulator set per sweep;
+                // head dims <= 160 / <= 192 on the instantiations that skip the zero padding (DEFF)
+                auto two = [&](auto deff_c) {
+                    constexpr int DEFF = decltype(deff_c)::value;
+                    static std::atomic<uint64_t> attr_dv{0}, attr_dk{0};
+                    int s2 = launch_kernel(fa::bwd_dkdv_kernel<T, D, 1, SOFTCAP, DROPOUT, DEFF, 1>, fa::smem_bytes_dkdv<D>(), attr_dv, bp.grid, 256, bp, stream);
+                    if (s2 == FA_OK)
+                        s2 = launch_kernel(fa::bwd_dkdv_kernel<T, D, 1, SOFTCAP, DROPOUT, DEFF, 2>, fa::smem_bytes_dkdv<D>(), attr_dk, bp.grid, 256, bp, stream);
+                    return s2;
+                };
+                if constexpr (!SOFTCAP && !DROPOUT) {
+                    st = bp.d <= 160 ? two(std::integral_constant<int, 160>{}) : bp.d <= 192 ? two(std::integral_constant<int, 192>{}) : two(std::integral_constant<int, 256>{});
+                } else {
+                    st = two(std::integral_constant<int, 256>{});
+                }
             } else {
                 st = one_block ? launch_kernel(fa::bwd_dkdv_kernel<T, D, 1, SOFTCAP, DROPOUT>, fa::smem_bytes_dkdv<D>(), attr1, bp.grid, 256, bp, stream)
                                : launch_kernel(fa::bwd_dkdv_kernel<T, D, NBK2, SOFTCAP, DROPOUT>, fa::smem_bytes_dkdv<D>(), attr, bp.grid, 256, bp, stream);
@@ -110,6 +126,11 @@ int run_bwd(fa::BParams bp, int rows_q_max, int rows_k_max, hipStream_t stream) 
                 static std::atomic<uint64_t> attr96{0};
                 st = bp.d <= 96 ? launch_kernel(fa::bwd_dq_kernel<T, D, NBQ, false, false, 96>, fa::smem_bytes_dq<D>(), attr96, bp.grid, 256, bp, stream)
                                 : launch_kernel(fa::bwd_dq_kernel<T, D, NBQ, false, false>, fa::smem_bytes_dq<D>(), attr, bp.grid, 256, bp, stream);
+            } else if constexpr (D == 256 && !SOFTCAP && !DROPOUT) {
+                static std::atomic<uint64_t> attr160{0}, attr192{0};
+                st = bp.d <= 160 ? launch_kernel(fa::bwd_dq_kernel<T, D, NBQ, false, false, 160>, fa::smem_bytes_dq<D>(), attr160, bp.grid, 256, bp, stream)
+                   : bp.d <= 192 ? launch_kernel(fa::bwd_dq_kernel<T, D, NBQ, false, false, 192>, fa::smem_bytes_dq<D>(), attr192, bp.grid, 256, bp, stream)
+                                 : launch_kernel(fa::bwd_dq_kernel<T, D, NBQ, false, false>, fa::smem_bytes_dq<D>(), attr, bp.grid, 256, bp, stream);
             } else {
                 st = launch_kernel(fa::bwd_dq_kernel<T, D, NBQ, SOFTCAP, DROPOUT>, fa::smem_bytes_dq<D>(), attr, bp.grid, 256, bp, stream);
             }

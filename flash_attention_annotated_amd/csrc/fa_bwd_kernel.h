@@ -65,9 +65,11 @@ __device__ __forceinline__ void drain_tiles(f32x16 (&a)[NB], f32x16 (&b)[NB]) {
 }
 template <int N>
 __device__ __forceinline__ void drain_acc(f32x16 (&a)[N]) {
-    static_assert(N == 2 || N == 4 || N == 8, "accumulator tiles per array");
+    static_assert(N == 2 || N == 4 || N == 5 || N == 6 || N == 8, "accumulator tiles per array");
     if constexpr (N == 2) asm volatile("s_nop 15\n\ts_nop 7" : "+a"(a[0]), "+a"(a[1]));
     else if constexpr (N == 4) asm volatile("s_nop 15\n\ts_nop 7" : "+a"(a[0]), "+a"(a[1]), "+a"(a[2]), "+a"(a[3]));
+    else if constexpr (N == 5) asm volatile("s_nop 15\n\ts_nop 7" : "+a"(a[0]), "+a"(a[1]), "+a"(a[2]), "+a"(a[3]), "+a"(a[4]));
+    else if constexpr (N == 6) asm volatile("s_nop 15\n\ts_nop 7" : "+a"(a[0]), "+a"(a[1]), "+a"(a[2]), "+a"(a[3]), "+a"(a[4]), "+a"(a[5]));
     else asm volatile("s_nop 15\n\ts_nop 7" : "+a"(a[0]), "+a"(a[1]), "+a"(a[2]), "+a"(a[3]), "+a"(a[4]), "+a"(a[5]),
                       "+a"(a[6]), "+a"(a[7]));
 }
@@ -260,14 +262,24 @@ __device__ __forceinline__ void bwd_point(const BParams &p, float x, float dp, f
 // dK / dV.  NB = 32-key blocks per wave: every Q / dO / Q^T / dO^T fragment read from LDS feeds NB MFMAs (the
 // one-block form moves 1 KiB of LDS per MFMA, which is the LDS bandwidth limit of the CU).
 // ------------------------------------------------------------------------------------------------------------------
-template <typename T, int D, int NB, bool SOFTCAP, bool DROPOUT = false, int DEFF = D>
+// PART (head-dim tile 256): 0 = dK and dV in one sweep; 1 = dV only (S, dV: no V operand, no dP); 2 = dK only (S, dP, dK).
+// At D = 256 both accumulator sets are 256 registers -- the whole AGPR file -- beside 128 registers of resident K / V
+// fragments: the one-sweep form spills its way through every tile (119 TFLOP/s of issued work at s8192, rocprofv3: 18.5 ms
+// of a 20.4 ms backward).  Two launches, each with ONE pinned accumulator set, recompute S once more (5 matrix products
+// instead of 4) and run without scratch traffic in the tile loop.
+template <typename T, int D, int NB, bool SOFTCAP, bool DROPOUT = false, int DEFF = D, int PART = 0>
 __global__ __launch_bounds__(256, 1) void bwd_dkdv_kernel(const BParams p) {
     constexpr int NT = 256;
+    constexpr bool DO_DK = PART != 1, DO_DV = PART != 2;
     constexpr int WKEYS = 32 * NB;             // keys per wave
     constexpr int BLOCK_K = 4 * WKEYS;         // keys per workgroup
     constexpr int BM = 64;                     // query rows per streamed tile
-    constexpr int KSTEPS = D / 16;
-    constexpr int DBLOCKS = D / 32;
+    // head-dim tile 256 with DEFF = 192 / 160 (head dims 129..192): the k-steps and accumulator blocks of the zero padding are
+    // left out of every product; LDS rows, staging and the epilogue keep the tile's 512-byte rows.  (The 128 tile's DEFF = 96
+    // only selects the generated loop: its C++ tile path keeps the full tile.)
+    constexpr int DE = D == 256 ? DEFF : D;
+    constexpr int KSTEPS = DE / 16;
+    constexpr int DBLOCKS = DE / 32;
     constexpr int CH_PER_ROW = D / 8;
     constexpr int TILE_BYTES = BM * D * 2;
     constexpr int CHUNKS = BM * CH_PER_ROW;
@@ -327,38 +339,42 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_kernel(const BParams p) {
             u32x4 a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
             if (key < sk && d0 < p.d) {
                 a = *(const u32x4 *)(kp + (int64_t)key * p.k_row_stride + d0);
-                b = *(const u32x4 *)(vp + (int64_t)key * p.v_row_stride + d0);
+                if constexpr (DO_DK) b = *(const u32x4 *)(vp + (int64_t)key * p.v_row_stride + d0);
             }
             kf[nb][ks] = a;
-            vf[nb][ks] = b;
+            vf[nb][ks] = b;  // (PART 1: never read)
         }
 
     // Accumulators pinned in AGPRs by asm MFMAs -- unless both sets would take ALL 256 AGPRs (D = 256): hipcc then has
     // no AGPR temporaries left and rotates the whole file around the asm statements; there only dV is pinned and dK
     // stays compiler-managed (measured: 5.8 -> 5.0 ms on b2 s4096 h8 d256).
-    constexpr bool PIN_ACC = 2 * NB * DBLOCKS * 16 < 256;  // dK (and dV)
+    constexpr bool PIN_ACC = (PART == 0 ? 2 : 1) * NB * DBLOCKS * 16 < 256;  // dK (and dV)
     // (D = 256 with dropout: the extra live state makes hipcc move the pinned tiles around inside MFMA hazard windows;
     //  that rare combination runs on compiler-managed accumulators)
-    constexpr bool PIN_DV = !(D == 256 && DROPOUT);
-    f32x16 dk_acc[NB * DBLOCKS], dv_acc[NB * DBLOCKS];  // [nb * DBLOCKS + db]
+    constexpr bool PIN_DV = PART != 0 || !(D == 256 && DROPOUT);
+    f32x16 dk_acc[DO_DK ? NB * DBLOCKS : 1], dv_acc[DO_DV ? NB * DBLOCKS : 1];  // [nb * DBLOCKS + db]
     {
         const u32x4 z4 = {0, 0, 0, 0};
 #pragma unroll
         for (int i = 0; i < NB * DBLOCKS; ++i) {
-            if constexpr (PIN_ACC) Mfma<T>::o_zero(dk_acc[i], z4);
-            else {
+            if constexpr (DO_DK) {
+                if constexpr (PIN_ACC) Mfma<T>::o_zero(dk_acc[i], z4);
+                else {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) dk_acc[i][e] = 0.f;
+                    for (int e = 0; e < 16; ++e) dk_acc[i][e] = 0.f;
+                }
             }
-            if constexpr (PIN_DV) Mfma<T>::o_zero(dv_acc[i], z4);
-            else {
+            if constexpr (DO_DV) {
+                if constexpr (PIN_DV) Mfma<T>::o_zero(dv_acc[i], z4);
+                else {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) dv_acc[i][e] = 0.f;
+                    for (int e = 0; e < 16; ++e) dv_acc[i][e] = 0.f;
+                }
             }
         }
         // (hipcc may spill an accumulator to scratch right here -- it does at D = 256: let the matrix pipe finish first)
-        if constexpr (PIN_ACC) drain_acc(dk_acc);
-        if constexpr (PIN_DV) drain_acc(dv_acc);
+        if constexpr (DO_DK && PIN_ACC) drain_acc(dk_acc);
+        if constexpr (DO_DV && PIN_DV) drain_acc(dv_acc);
     }
 
     // ---- Q / dO tile staging: rows clamped into the sequence (clamped rows are masked).  LDS-DMA
@@ -456,7 +472,7 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_kernel(const BParams p) {
         // the generated asm block (fa_bwd_loop_gen.h; same LDS layout and barrier protocol, so the four waves choose
         // independently).  The tile behind a run must belong to the same head (the block prefetches it through the head's
         // buffer descriptors); the run's tiles lie fully inside the sequence.
-        if constexpr ((D == 128 || D == 64) && NB == 1 && !SOFTCAP && !DROPOUT && DMA && !(FA_BWD_ABLATE & 1)) {
+        if constexpr ((D == 128 || D == 64) && NB == 1 && !SOFTCAP && !DROPOUT && DMA && PART == 0 && !(FA_BWD_ABLATE & 1)) {
             const int row0 = tile_row0(it);
             const int left = num_m - it % num_m;  // tiles of this head from `it` on
             int hi_row = sq - BM;
@@ -545,18 +561,32 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_kernel(const BParams p) {
                 };
                 u32x4 qa_r[PF + 1], ga_r[PF + 1];
 #pragma unroll
-                for (int i = 0; i < PF; ++i) { qa_r[i] = row_frag(qbuf, i); ga_r[i] = row_frag(gbuf, i); }
+                for (int i = 0; i < PF; ++i) {
+                    qa_r[i] = row_frag(qbuf, i);
+                    if constexpr (DO_DK) ga_r[i] = row_frag(gbuf, i);
+                }
+                if constexpr (!DO_DK) {  // dV only: dP is never formed (bwd_point's dS is dead code there)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) dp[nb][e] = 0.f;
+                }
 #pragma unroll
                 for (int ks = 0; ks < KSTEPS; ++ks) {
                     if (ks + PF < KSTEPS) {
                         qa_r[(ks + PF) % (PF + 1)] = row_frag(qbuf, ks + PF);
-                        ga_r[(ks + PF) % (PF + 1)] = row_frag(gbuf, ks + PF);
+                        if constexpr (DO_DK) ga_r[(ks + PF) % (PF + 1)] = row_frag(gbuf, ks + PF);
                     }
-                    const u32x4 qa = qa_r[ks % (PF + 1)], ga = ga_r[ks % (PF + 1)];
+                    const u32x4 qa = qa_r[ks % (PF + 1)];
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) {
-                        if (ks == 0) { BMfma<T>::s_first_v(s[nb], qa, kf[nb][ks]); BMfma<T>::s_first_v(dp[nb], ga, vf[nb][ks]); }
-                        else { BMfma<T>::s_acc_v(s[nb], qa, kf[nb][ks]); BMfma<T>::s_acc_v(dp[nb], ga, vf[nb][ks]); }
+                        if (ks == 0) BMfma<T>::s_first_v(s[nb], qa, kf[nb][ks]);
+                        else BMfma<T>::s_acc_v(s[nb], qa, kf[nb][ks]);
+                        if constexpr (DO_DK) {
+                            const u32x4 ga = ga_r[ks % (PF + 1)];
+                            if (ks == 0) BMfma<T>::s_first_v(dp[nb], ga, vf[nb][ks]);
+                            else BMfma<T>::s_acc_v(dp[nb], ga, vf[nb][ks]);
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -630,21 +660,29 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_kernel(const BParams p) {
                 constexpr int NT2 = 2 * DBLOCKS;
                 u32x4 gt_r[PF + 1], qt_r[PF + 1];
 #pragma unroll
-                for (int i = 0; i < PF; ++i) { gt_r[i] = tr_frag(gbuf, i); qt_r[i] = tr_frag(qbuf, i); }
+                for (int i = 0; i < PF; ++i) {
+                    if constexpr (DO_DV) gt_r[i] = tr_frag(gbuf, i);
+                    if constexpr (DO_DK) qt_r[i] = tr_frag(qbuf, i);
+                }
 #pragma unroll
                 for (int t = 0; t < NT2; ++t) {
                     if (t + PF < NT2) {
-                        gt_r[(t + PF) % (PF + 1)] = tr_frag(gbuf, t + PF);
-                        qt_r[(t + PF) % (PF + 1)] = tr_frag(qbuf, t + PF);
+                        if constexpr (DO_DV) gt_r[(t + PF) % (PF + 1)] = tr_frag(gbuf, t + PF);
+                        if constexpr (DO_DK) qt_r[(t + PF) % (PF + 1)] = tr_frag(qbuf, t + PF);
                     }
-                    const u32x4 gt = gt_r[t % (PF + 1)], qt = qt_r[t % (PF + 1)];
                     const int db = t >> 1, st = t & 1;
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) {  // (s_nop 1 in front: VALU-packed P / dS -> MFMA operand)
-                        if constexpr (PIN_DV) Mfma<T>::o_acc_pad(dv_acc[nb * DBLOCKS + db], gt, pf[nb][st]);
-                        else dv_acc[nb * DBLOCKS + db] = Elem<T>::mma(gt, pf[nb][st], dv_acc[nb * DBLOCKS + db]);
-                        if constexpr (PIN_ACC) Mfma<T>::o_acc_pad(dk_acc[nb * DBLOCKS + db], qt, dsf[nb][st]);
-                        else dk_acc[nb * DBLOCKS + db] = Elem<T>::mma(qt, dsf[nb][st], dk_acc[nb * DBLOCKS + db]);
+                        if constexpr (DO_DV) {
+                            const u32x4 gt = gt_r[t % (PF + 1)];
+                            if constexpr (PIN_DV) Mfma<T>::o_acc_pad(dv_acc[nb * DBLOCKS + db], gt, pf[nb][st]);
+                            else dv_acc[nb * DBLOCKS + db] = Elem<T>::mma(gt, pf[nb][st], dv_acc[nb * DBLOCKS + db]);
+                        }
+                        if constexpr (DO_DK) {
+                            const u32x4 qt = qt_r[t % (PF + 1)];
+                            if constexpr (PIN_ACC) Mfma<T>::o_acc_pad(dk_acc[nb * DBLOCKS + db], qt, dsf[nb][st]);
+                            else dk_acc[nb * DBLOCKS + db] = Elem<T>::mma(qt, dsf[nb][st], dk_acc[nb * DBLOCKS + db]);
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -656,13 +694,13 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_kernel(const BParams p) {
     }
 
     // ---- epilogue: dK^T / dV^T registers (lane = key, registers = head dim) -> LDS -> coalesced rows ------------
-    if constexpr (PIN_ACC) drain_acc(dk_acc);  // asm MFMA results -> VALU readers
-    if constexpr (PIN_DV) drain_acc(dv_acc);
+    if constexpr (DO_DK && PIN_ACC) drain_acc(dk_acc);  // asm MFMA results -> VALU readers
+    if constexpr (DO_DV && PIN_DV) drain_acc(dv_acc);
     T *dkp = (T *)p.dk + sq_.dk_base + (int64_t)kv_head * p.dk_head_stride;
     T *dvp = (T *)p.dv + sq_.dv_base + (int64_t)kv_head * p.dv_head_stride;
     char *obuf = smem + wave * (32 * O_ROW_BYTES);
 #pragma unroll
-    for (int which = 0; which < 2; ++which) {
+    for (int which = DO_DK ? 0 : 1; which < (DO_DV ? 2 : 1); ++which) {
         const float f = which == 0 ? p.out_scale : 1.f;
         T *dst = which == 0 ? dkp : dvp;
         const int64_t rs = which == 0 ? p.dk_row_stride : p.dv_row_stride;
@@ -672,7 +710,7 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_kernel(const BParams p) {
             for (int db = 0; db < DBLOCKS; ++db)
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
-                    const f32x16 &acc = which == 0 ? dk_acc[nb * DBLOCKS + db] : dv_acc[nb * DBLOCKS + db];
+                    const f32x16 &acc = (which == 0 ? dk_acc : dv_acc)[(which == 0 ? DO_DK : DO_DV) ? nb * DBLOCKS + db : 0];
                     u32x2 w;
                     w[0] = Elem<T>::pack2(acc[4 * g4] * f, acc[4 * g4 + 1] * f);
                     w[1] = Elem<T>::pack2(acc[4 * g4 + 2] * f, acc[4 * g4 + 3] * f);
@@ -711,8 +749,9 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_kernel(const BParams p) {
     constexpr int NT = 256;
     constexpr int WROWS = 32 * NB;
     constexpr int BLOCK_M = 4 * WROWS;
-    constexpr int KSTEPS = D / 16;
-    constexpr int DBLOCKS = D / 32;
+    constexpr int DE = D == 256 ? DEFF : D;    // (see bwd_dkdv_kernel)
+    constexpr int KSTEPS = DE / 16;
+    constexpr int DBLOCKS = DE / 32;
     constexpr int CH_PER_ROW = D / 8;
     constexpr int TILE_BYTES = BLOCK_N * D * 2;
     constexpr int CHUNKS = BLOCK_N * CH_PER_ROW;
