@@ -334,7 +334,12 @@ int effective_variant(const fa_fwd_params *p) {
     int variant = p->kernel_variant ? p->kernel_variant : g_default_variant.load();
     if (variant < 0 || variant > 3) variant = 0;
     if (p->p_dropout > 0.f) return 1;  // dropout lives in the compiler-scheduled shape only
-    if (generic_only(p)) return 1;  // fwd_kernel, EXTRA instantiations: 8 waves x 32 rows (4 x 32 at head-dim tile 256)
+    if (generic_only(p)) {
+        // fwd_kernel, EXTRA instantiations: 8 waves x 32 rows (4 x 32 at head-dim tile 256) -- except a V head dim of its own
+        // on the wide tile, which dispatch_variant<T, 256> hands to the generated-loop kernel when the features are plain
+        if (p->attention_chunk == 0 && head_dim_tile(wide_dim(p)) == 256 && variant == 0) return 0;
+        return 1;
+    }
     if (variant == 0 || variant == 3) {
         if (p->block_table) variant = 1;
         else if (!p->cu_seqlens_q && p->seqlen_q <= 128) variant = 2;
@@ -587,6 +592,17 @@ int dispatch_variant(const fa::KParams &kp, bool softcap, int variant, hipStream
     // variant 1  : 8 waves x 32 rows (BLOCK_M 256), two waves per SIMD (fa_fwd_kernel.h)
     // variant 2  : 4 waves x 32 rows (BLOCK_M 128)
     // D = 256 does not fit the w64 register budget (O alone would be 256 registers): 4 waves x 32 rows.
+    if constexpr (D == 256) {
+        // a V head dim of its own on the wide tile (192 / 128, or q/k <= 64 beside v in (128, 256]) with plain features: the
+        // generated-loop kernel, head-dim tile by the larger of the two (fa_fwd_kernel_d256.h reads p.dv for V and O)
+        if (kp.dv != kp.d && kp.chunk == 0 && (variant == 0 || variant == 3) && !softcap && !kp.alibi && !kp.block_table &&
+            kp.num_splits <= 1 && kp.rp_dropout == 1.f) {
+            const int w = std::max(kp.d, kp.dv);
+            if (w <= 160) return launch_d256<T, 160>(kp, stream);
+            if (w <= 192) return launch_d256<T, 192>(kp, stream);
+            return launch_d256<T, 256>(kp, stream);
+        }
+    }
     if (kp.chunk > 0 || kp.dv != kp.d) {
         // attention_chunk / a V head dim of its own (FA3 surface, ABI v12): the EXTRA instantiations of the compiler-scheduled
         // shape, 8 waves x 32 rows (4 at head-dim tile 256); no dropout on that surface (fa_fwd_validate)

@@ -156,7 +156,9 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_d256(const KParams p) {
         return dsc;
     };
     const int dw = min(p.d, D);
-    const u32x4 kdesc = make_desc(kp, k_rs, sk, dw), vdesc = make_desc(vp, v_rs, sk, dw);
+    // (V and O may have a head dim of their own, p.dv: FA3 headdim_v, e.g. 192 / 128 -- its chunks past dv read as zeros, the
+    //  O columns they would produce are not stored; p.dv = p.d everywhere else)
+    const u32x4 kdesc = make_desc(kp, k_rs, sk, dw), vdesc = make_desc(vp, v_rs, sk, min(p.dv, D));
     // piece i of this wave = LDS bytes [wave * 8 KiB + 1024 i, +1024) of a tile image = rows 16 wave + 2 i, + 1; lane l holds the
     // 16-byte slot l of the piece; head-dim chunks past d read as zeros (offset pushed past num_records)
     uint32_t koff[8], voff[8];
@@ -165,9 +167,9 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_d256(const KParams p) {
         const int slot = wave * 512 + i * 64 + lane;
         const int row = slot / CH_PER_ROW;
         const int ch = (slot % CH_PER_ROW) ^ (((row & 3) << 2) | ((row >> 2) & 3));   // inverse of lds_off<256>
-        const bool in = ch * 8 < p.d;
+        const bool in = ch * 8 < p.d, in_v = ch * 8 < p.dv;
         koff[i] = (in ? (uint32_t)(row * k_rs + ch * 8) * 2u : 0x7ffffff0u) - 1024u * (i & 3);
-        voff[i] = (in ? (uint32_t)(row * v_rs + ch * 8) * 2u : 0x7ffffff0u) - 1024u * (i & 3);
+        voff[i] = (in_v ? (uint32_t)(row * v_rs + ch * 8) * 2u : 0x7ffffff0u) - 1024u * (i & 3);
     }
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
     const uint32_t lds_wave = lds0 + wave * 8192;
@@ -445,7 +447,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_d256(const KParams p) {
         for (int i = 0; i < NCH; ++i) {
             const int c = lane_e + i * 64;
             const int row = c / CH_PER_ROW, ch = c % CH_PER_ROW;
-            if (wrow + row < sq && ch * 8 < p.d) *(u32x4 *)(op + (int64_t)(wrow + row) * p.o_row_stride + ch * 8) = val[i];
+            if (wrow + row < sq && ch * 8 < p.dv) *(u32x4 *)(op + (int64_t)(wrow + row) * p.o_row_stride + ch * 8) = val[i];
         }
     }
 }
