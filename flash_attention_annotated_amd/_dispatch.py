@@ -126,6 +126,7 @@ def launch_bwd(dout, q, k, v, out, lse, dq, dk, dv, softmax_d, *, varlen, batch,
             setattr(prm, f"{name}_head_stride", t.stride(2))
         prm.total_q = prm.total_k = 0
         prm.h, prm.h_k, prm.d = q.shape[2], k.shape[2], q.shape[3]
+    prm.d_v = int(v.shape[-1]) if v.shape[-1] != q.shape[-1] else 0  # FA3 headdim_v (include/fa_bwd.h, ABI v12)
     prm.softmax_d_row_len = softmax_d.shape[-1]
     prm.b, prm.seqlen_q, prm.seqlen_k = int(batch), int(max_seqlen_q), int(max_seqlen_k)
     prm.dtype = _DT[q.dtype]

@@ -174,7 +174,7 @@ class FaBwdParams(ctypes.Structure):
         + [("is_causal", ctypes.c_int32), ("window_size_left", ctypes.c_int32), ("window_size_right", ctypes.c_int32)]
         + [("alibi_slopes", ctypes.c_void_p), ("alibi_slopes_batch_stride", ctypes.c_int64)]
         + [("deterministic", ctypes.c_int32), ("p_dropout", ctypes.c_float), ("rng_state", ctypes.c_void_p)]
-        + [("flags", ctypes.c_int32), ("reserved2", ctypes.c_int32)]
+        + [("flags", ctypes.c_int32), ("d_v", ctypes.c_int32)]
     )
 
 

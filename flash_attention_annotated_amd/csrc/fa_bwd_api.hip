@@ -99,7 +99,8 @@ int run_bwd(fa::BParams bp, int rows_q_max, int rows_k_max, hipStream_t stream) 
                     return s2;
                 };
                 if constexpr (!SOFTCAP && !DROPOUT) {
-                    st = bp.d <= 160 ? two(std::integral_constant<int, 160>{}) : bp.d <= 192 ? two(std::integral_constant<int, 192>{}) : two(std::integral_constant<int, 256>{});
+                    const int w = std::max(bp.d, bp.d_v);
+                    st = w <= 160 ? two(std::integral_constant<int, 160>{}) : w <= 192 ? two(std::integral_constant<int, 192>{}) : two(std::integral_constant<int, 256>{});
                 } else {
                     st = two(std::integral_constant<int, 256>{});
                 }
@@ -128,8 +129,9 @@ int run_bwd(fa::BParams bp, int rows_q_max, int rows_k_max, hipStream_t stream) 
                                 : launch_kernel(fa::bwd_dq_kernel<T, D, NBQ, false, false>, fa::smem_bytes_dq<D>(), attr, bp.grid, 256, bp, stream);
             } else if constexpr (D == 256 && !SOFTCAP && !DROPOUT) {
                 static std::atomic<uint64_t> attr160{0}, attr192{0};
-                st = bp.d <= 160 ? launch_kernel(fa::bwd_dq_kernel<T, D, NBQ, false, false, 160>, fa::smem_bytes_dq<D>(), attr160, bp.grid, 256, bp, stream)
-                   : bp.d <= 192 ? launch_kernel(fa::bwd_dq_kernel<T, D, NBQ, false, false, 192>, fa::smem_bytes_dq<D>(), attr192, bp.grid, 256, bp, stream)
+                const int w = std::max(bp.d, bp.d_v);
+                st = w <= 160 ? launch_kernel(fa::bwd_dq_kernel<T, D, NBQ, false, false, 160>, fa::smem_bytes_dq<D>(), attr160, bp.grid, 256, bp, stream)
+                   : w <= 192 ? launch_kernel(fa::bwd_dq_kernel<T, D, NBQ, false, false, 192>, fa::smem_bytes_dq<D>(), attr192, bp.grid, 256, bp, stream)
                                  : launch_kernel(fa::bwd_dq_kernel<T, D, NBQ, false, false>, fa::smem_bytes_dq<D>(), attr, bp.grid, 256, bp, stream);
             } else {
                 st = launch_kernel(fa::bwd_dq_kernel<T, D, NBQ, SOFTCAP, DROPOUT>, fa::smem_bytes_dq<D>(), attr, bp.grid, 256, bp, stream);
@@ -143,7 +145,7 @@ int run_bwd(fa::BParams bp, int rows_q_max, int rows_k_max, hipStream_t stream) 
 template <typename T>
 int dispatch_bwd(const fa::BParams &bp, bool softcap, int sq, int sk, hipStream_t stream) {
     const bool drop = bp.rp_dropout != 1.f;  // p > 0 (never together with softcap: fa_bwd_validate)
-    switch (head_dim_tile_b(bp.d)) {
+    switch (head_dim_tile_b(std::max(bp.d, bp.d_v))) {
         case 64:
             if (drop) return run_bwd<T, 64, false, true>(bp, sq, sk, stream);
             return softcap ? run_bwd<T, 64, true>(bp, sq, sk, stream) : run_bwd<T, 64, false>(bp, sq, sk, stream);
@@ -171,6 +173,8 @@ int fa_bwd_validate(const fa_bwd_params *p) {
     if (p->p_dropout > 0.f && p->softcap > 0.f) return FA_ERR_UNSUPPORTED;  // "Softcapping does not support dropout for now"
     if (p->b <= 0 || p->h <= 0 || p->h_k <= 0 || p->seqlen_q < 0 || p->seqlen_k < 0) return FA_ERR_BAD_SHAPE;
     if (p->d <= 0 || p->d > 256 || p->d % 8 != 0) return FA_ERR_BAD_HEAD_DIM;
+    if (p->d_v < 0 || p->d_v % 8 != 0) return FA_ERR_BAD_HEAD_DIM;
+    if (p->d_v > 0 && p->d_v != p->d && (p->d_v > 256 || std::max(p->d, p->d_v) <= 128)) return FA_ERR_UNSUPPORTED;  // wide tile only
     if (p->h % p->h_k != 0) return FA_ERR_BAD_HEADS;
     if ((p->cu_seqlens_q == nullptr) != (p->cu_seqlens_k == nullptr)) return FA_ERR_BAD_SHAPE;
     if (p->cu_seqlens_q && (p->total_q < 0 || p->total_k < 0)) return FA_ERR_BAD_SHAPE;
@@ -228,6 +232,7 @@ int fa_bwd(const fa_bwd_params *p, void *stream_) {
     bp.dv_batch_stride = p->dv_batch_stride; bp.dv_row_stride = p->dv_row_stride; bp.dv_head_stride = p->dv_head_stride;
     bp.dsum_row_len = p->softmax_d_row_len;
     bp.b = p->b; bp.seqlen_q = p->seqlen_q; bp.seqlen_k = p->seqlen_k; bp.h = p->h; bp.h_k = p->h_k; bp.d = p->d;
+    bp.d_v = (p->d_v > 0) ? p->d_v : p->d;
     bp.total_q = p->total_q;
     bp.h_ratio = p->h / p->h_k;
 

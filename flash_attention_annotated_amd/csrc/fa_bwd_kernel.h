@@ -96,6 +96,7 @@ struct BParams {
     int64_t dv_batch_stride, dv_row_stride, dv_head_stride;
     int64_t dsum_row_len;
     int32_t b, seqlen_q, seqlen_k, h, h_k, d, total_q;
+    int32_t d_v;           // head dim of v / o / dout / dv (= d unless the FA3 headdim_v differs; wide tile only: fa_bwd_validate)
     int32_t h_ratio;
     int32_t num_blocks;    // blocks per (batch, head): key blocks (dK/dV) or query blocks (dQ)
     int32_t num_tiles;     // work list length
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(256) void bwd_dot_kernel(const BParams p) {
         const T *op = (const T *)p.o + o_off + (int64_t)head * p.o_head_stride;
         const T *gp = (const T *)p.dout + do_off + (int64_t)head * p.do_head_stride;
         float acc = 0.f;
-        for (int c = sub * 8; c < p.d; c += LPR * 8) {
+        for (int c = sub * 8; c < p.d_v; c += LPR * 8) {
             const u32x4 a = *(const u32x4 *)(op + c);
             const u32x4 g = *(const u32x4 *)(gp + c);
             const uint32_t aw[4] = {a[0], a[1], a[2], a[3]}, gw[4] = {g[0], g[1], g[2], g[3]};
@@ -337,9 +338,9 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_kernel(const BParams p) {
             const int key = key_w0 + 32 * nb + r;
             const int d0 = ks * 16 + hh * 8;
             u32x4 a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
-            if (key < sk && d0 < p.d) {
-                a = *(const u32x4 *)(kp + (int64_t)key * p.k_row_stride + d0);
-                if constexpr (DO_DK) b = *(const u32x4 *)(vp + (int64_t)key * p.v_row_stride + d0);
+            if (key < sk && d0 < p.d) a = *(const u32x4 *)(kp + (int64_t)key * p.k_row_stride + d0);
+            if constexpr (DO_DK) {
+                if (key < sk && d0 < p.d_v) b = *(const u32x4 *)(vp + (int64_t)key * p.v_row_stride + d0);
             }
             kf[nb][ks] = a;
             vf[nb][ks] = b;  // (PART 1: never read)
@@ -430,9 +431,9 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_kernel(const BParams p) {
                 const int c = tid + i * NT;
                 const int row = min(row0 + c / CH_PER_ROW, sq - 1);
                 const int ch = c % CH_PER_ROW;
-                const int col = (ch * 8 < p.d) ? ch * 8 : 0;
+                const int col = (ch * 8 < p.d) ? ch * 8 : 0, colg = (ch * 8 < p.d_v) ? ch * 8 : 0;
                 qreg[i] = *(const u32x4 *)(qp + (int64_t)row * p.q_row_stride + col);
-                greg[i] = *(const u32x4 *)(gp + (int64_t)row * p.do_row_stride + col);
+                greg[i] = *(const u32x4 *)(gp + (int64_t)row * p.do_row_stride + colg);
             }
         }
         if (tid < 2 * BM) {  // threads 0..63: LSE (log2 units), 64..127: D
@@ -722,7 +723,7 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_kernel(const BParams p) {
                 const int c = lane + i * 64;
                 const int row = c / CH_PER_ROW, ch = c % CH_PER_ROW;
                 const int key = key_w0 + 32 * nb + row;
-                if (key < sk && ch * 8 < p.d) {
+                if (key < sk && ch * 8 < (which == 0 ? p.d : p.d_v)) {
                     const u32x4 val = *(const u32x4 *)(obuf + row * O_ROW_BYTES + ch * 16);
                     *(u32x4 *)(dst + (int64_t)key * rs + ch * 8) = val;
                 }
@@ -809,10 +810,8 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_kernel(const BParams p) {
         for (int ks = 0; ks < KSTEPS; ++ks) {
             const int d0 = ks * 16 + hh * 8;
             u32x4 a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
-            if (my_row < sq && d0 < p.d) {
-                a = *(const u32x4 *)(qp + (int64_t)my_row * p.q_row_stride + d0);
-                b = *(const u32x4 *)(gp + (int64_t)my_row * p.do_row_stride + d0);
-            }
+            if (my_row < sq && d0 < p.d) a = *(const u32x4 *)(qp + (int64_t)my_row * p.q_row_stride + d0);
+            if (my_row < sq && d0 < p.d_v) b = *(const u32x4 *)(gp + (int64_t)my_row * p.do_row_stride + d0);
             qf[nb][ks] = a;
             gf[nb][ks] = b;
             asm volatile("; pin Q" : "+a"(qf[nb][ks]));   // B operands of every score MFMA: AGPR residents
@@ -881,9 +880,9 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_kernel(const BParams p) {
                 const int c = tid + i * NT;
                 const int row = min(k0 + c / CH_PER_ROW, sk - 1);
                 const int ch = c % CH_PER_ROW;
-                const int col = (ch * 8 < p.d) ? ch * 8 : 0;
+                const int col = (ch * 8 < p.d) ? ch * 8 : 0, colv = (ch * 8 < p.d_v) ? ch * 8 : 0;
                 kreg[i] = *(const u32x4 *)(kp + (int64_t)row * p.k_row_stride + col);
-                vreg[i] = *(const u32x4 *)(vp + (int64_t)row * p.v_row_stride + col);
+                vreg[i] = *(const u32x4 *)(vp + (int64_t)row * p.v_row_stride + colv);
             }
         }
     };

@@ -60,8 +60,9 @@ def _bwd(dout, q, k, v, out, softmax_lse, dq=None, dk=None, dv=None, cu_seqlens_
     """mha_bwd, hopper/flash_api.cpp:1259-1570, on the FA2-shaped backward of this build (16-bit types)."""
     if seqused_q is not None or seqused_k is not None:
         raise RuntimeError("This flash attention build does not support seqused_q / seqused_k in the backward.")
-    if v.shape[-1] != q.shape[-1]:  # (the reference's backward takes it, hopper/flash_api.cpp:1345-1369)
-        raise RuntimeError("This flash attention build does not support a V headdim different from the Q/K headdim in the backward.")
+    if v.shape[-1] != q.shape[-1]:
+        return _bwd_own_dv(dout, q, k, v, out, softmax_lse, dq, dk, dv, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k,
+                           softmax_scale, is_causal, window_size_left, window_size_right, softcap, deterministic)
     if softmax_scale is None:
         softmax_scale = q.shape[-1] ** (-0.5)
     # window normalisation of the FA3 entry points (hopper/flash_api.cpp:1360-1361, as :796-797 of the forward): a side that
@@ -86,6 +87,67 @@ def _bwd(dout, q, k, v, out, softmax_lse, dq=None, dk=None, dv=None, cu_seqlens_
                                                    None, None)
     e = torch.empty(0, dtype=torch.float32, device=q.device)  # softmax_lse_log2, dq_accum, dk_accum, dv_accum: none here
     return dq, dk, dv, sd, e, e.clone(), e.clone(), e.clone()
+
+
+def _bwd_own_dv(dout, q, k, v, out, softmax_lse, dq, dk, dv, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k,
+                softmax_scale, is_causal, window_size_left, window_size_right, softcap, deterministic):
+    """mha_bwd with a V head dim of its own (hopper/flash_api.cpp:1345-1369, 1399-1412, 1462-1464: v / out / dout / dv carry
+    head_size_v, the kernels round both dims to the larger).  Built for the wide tile: max(d, dv) in (128, 256]."""
+    from . import _dispatch
+
+    def check(cond, msg):
+        if not cond:
+            raise RuntimeError(msg)
+    d, d_v = q.shape[-1], v.shape[-1]
+    check(q.dtype in (torch.float16, torch.bfloat16), "FlashAttention only support fp16 and bf16 data type")
+    for t, n in ((k, "key"), (v, "value"), (out, "out"), (dout, "dout")):
+        check(t.dtype == q.dtype, f"query and {n} must have the same dtype")
+    check(d % 8 == 0, "head_size should be a multiple of 8")
+    check(d_v % 8 == 0, "head_size_v should be a multiple of 8")
+    check(max(d, d_v) <= 256, "FlashAttention backward only supports head dimension at most 256")
+    check(max(d, d_v) > 128, "This flash attention build supports a V headdim different from the Q/K headdim in the backward "
+                             "only when the larger of the two is above 128.")
+    check(k.shape[-1] == d and tuple(v.shape[:-1]) == tuple(k.shape[:-1]), "k / v shapes do not match")
+    check(tuple(out.shape) == tuple(q.shape[:-1]) + (d_v,) and tuple(dout.shape) == tuple(out.shape), "out / dout must be (..., head_size_v)")
+    varlen = cu_seqlens_q is not None
+    if softmax_scale is None:
+        softmax_scale = d ** (-0.5)
+    sq_max = int(max_seqlen_q) if varlen else q.shape[1]
+    sk_max = int(max_seqlen_k) if varlen else k.shape[1]
+    if window_size_left >= sk_max - 1:
+        window_size_left = -1
+    if window_size_right >= sq_max - 1:
+        window_size_right = -1
+    if is_causal:
+        window_size_right = 0
+
+    def grad(given, like, name):
+        if given is None:
+            return torch.empty_like(like)
+        check(given.dtype == like.dtype and given.is_cuda and given.stride(-1) == 1 and tuple(given.shape) == tuple(like.shape),
+              f"{name} must have the dtype, device and shape of its tensor")
+        return given
+    dq, dk, dv = grad(dq, q, "dq"), grad(dk, k, "dk"), grad(dv, v, "dv")
+    batch = cu_seqlens_q.numel() - 1 if varlen else q.shape[0]
+    h = q.shape[-2]
+    with torch.cuda.device(q.device):
+        rows = q.shape[0] if varlen else (sq_max + 127) // 128 * 128
+        softmax_d = torch.empty(((h, rows + 128 * batch) if varlen else (batch, h, rows)), dtype=torch.float32, device=q.device)
+        if q.numel() > 0 and k.numel() > 0:
+            ins = [x if _dispatch.aligned(x) else x.contiguous() for x in (dout, q, k, v, out)]
+            outs = [x if _dispatch.aligned(x) else torch.empty_like(x, memory_format=torch.contiguous_format) for x in (dq, dk, dv)]
+            lse = softmax_lse if softmax_lse.is_contiguous() else softmax_lse.contiguous()
+            _dispatch.launch_bwd(*ins, lse, *outs, softmax_d, varlen=varlen, batch=batch, max_seqlen_q=sq_max, max_seqlen_k=sk_max,
+                                 softmax_scale=softmax_scale, causal=is_causal, window_left=window_size_left,
+                                 window_right=window_size_right, softcap=softcap, cu_seqlens_q=cu_seqlens_q,
+                                 cu_seqlens_k=cu_seqlens_k, deterministic=deterministic, fa3_window=True)
+            for dst, src in zip((dq, dk, dv), outs):
+                if dst is not src:
+                    dst.copy_(src)
+        else:
+            dq.zero_(); dk.zero_(); dv.zero_(); softmax_d.zero_()
+    e = torch.empty(0, dtype=torch.float32, device=q.device)
+    return dq, dk, dv, softmax_d, e, e.clone(), e.clone(), e.clone()
 
 
 def _fwd_combine(out_partial, lse_partial, out=None, out_dtype=None):

@@ -75,7 +75,10 @@ typedef struct fa_bwd_params {
     float p_dropout;       /* as fa_fwd_params; rng_state must be the pair the forward used */
     const uint64_t *rng_state;
     int32_t flags;         /* FA_FLAG_* as fa_fwd_params (FA_FLAG_FA3_WINDOW) */
-    int32_t reserved2;
+    /* ABI v12 -- head dim of v / o / dout / dv when it differs from d (FA3 headdim_v, hopper/flash_api.cpp:1345-1369:
+     * the reference's backward rounds both to the larger): 0 = d.  Built for the wide head-dim tile only (max(d, d_v) in
+     * (128, 256], e.g. 192 / 128); other pairs return FA_ERR_UNSUPPORTED. */
+    int32_t d_v;
 } fa_bwd_params;
 
 /* Validate and enqueue the backward on `stream`.  Returns FA_OK or a negative fa_status; asynchronous. */

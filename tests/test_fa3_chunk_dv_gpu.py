@@ -145,12 +145,55 @@ def test_rejections_and_backward():
     v = torch.randn(1, 16, 2, 64, dtype=torch.bfloat16, device=DEV)
     with pytest.raises(RuntimeError, match="If V headdim is different from Q/K dim"):
         fa3.flash_attn_func(q, q, v)                                    # hopper/flash_api.cpp:783-786
-    q192 = torch.randn(1, 16, 2, 192, dtype=torch.bfloat16, device=DEV, requires_grad=True)
+    q64 = torch.randn(1, 16, 2, 64, dtype=torch.bfloat16, device=DEV, requires_grad=True)
     v128 = torch.randn(1, 16, 2, 128, dtype=torch.bfloat16, device=DEV)
-    out = fa3.flash_attn_func(q192, q192.detach(), v128)
-    with pytest.raises(RuntimeError, match="V headdim different from the Q/K headdim in the backward"):
+    out = fa3.flash_attn_func(q64, q64.detach(), v128)
+    with pytest.raises(RuntimeError, match="only when the larger of the two is above 128"):
         out.sum().backward()
     qc = torch.randn(1, 16, 2, 64, dtype=torch.bfloat16, device=DEV, requires_grad=True)
     oc = fa3.flash_attn_func(qc, qc.detach(), qc.detach(), attention_chunk=4)
     with pytest.raises(AssertionError, match="attention_chunk"):       # hopper/flash_attn_interface.py: backward has no chunk
         oc.sum().backward()
+
+
+@pytest.mark.parametrize("varlen", [False, True])
+@pytest.mark.parametrize("causal,window", [(False, (-1, -1)), (True, (-1, -1)), (False, (60, 20))])
+@pytest.mark.parametrize("d,dv,dtype", [(192, 128, torch.bfloat16), (160, 128, torch.float16), (136, 104, torch.bfloat16), (64, 256, torch.bfloat16)])
+def test_backward_with_own_v_head_dim(d, dv, dtype, causal, window, varlen):
+    """dq / dk / dv for a V head dim that differs from the Q / K one (hopper/flash_api.cpp:1345-1369; the `dv` axis of the
+    backward half of hopper/test_flash_attn.py:225-286), contract |g - g_ref| <= 3 |g_pt - g_ref| + atol (:281-286)."""
+    fa3 = _fa3()
+    torch.manual_seed(d + dv + int(causal))
+    b, sq, sk, h, hk = 2, 200, 328, 4, 2
+    q = torch.randn(b, sq, h, d, dtype=dtype)
+    k = torch.randn(b, sk, hk, d, dtype=dtype)
+    v = torch.randn(b, sk, hk, dv, dtype=dtype)
+    g = torch.randn(b, sq, h, dv, dtype=dtype)
+    kw = dict(causal=causal, window_size=window)
+    qd, kd, vd = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
+    if not varlen:
+        out = fa3.flash_attn_func(qd, kd, vd, **kw)
+        got = torch.autograd.grad(out, (qd, kd, vd), g.to(DEV))
+        qm = km = None
+    else:
+        lens_q, lens_k = torch.tensor([sq, sq - 37]), torch.tensor([sk - 50, sk])
+        qm = torch.arange(sq).view(1, -1) < lens_q.view(-1, 1)
+        km = torch.arange(sk).view(1, -1) < lens_k.view(-1, 1)
+        qu, cu_q, mq = _unpad(qd, qm)
+        ku, cu_k, mk = _unpad(kd, km)
+        vu, _, _ = _unpad(vd, km)
+        gu, _, _ = _unpad(g.to(DEV), qm)
+        ou = fa3.flash_attn_varlen_func(qu, ku, vu, cu_q.to(DEV), cu_k.to(DEV), mq, mk, **kw)
+        got = torch.autograd.grad(ou, (qd, kd, vd), gu)
+
+    def oracle_grads(**extra):
+        ql, kl, vl = (t.clone().requires_grad_(True) for t in (q, k, v))
+        o, _ = oracle.attention_ref(ql, kl, vl, qm, km, **kw, **extra)
+        gg = g if qm is None else g.masked_fill(~qm.view(b, sq, 1, 1), 0)
+        return torch.autograd.grad(o, (ql, kl, vl), gg)
+    ref, pt = oracle_grads(), oracle_grads(upcast=False, reorder_ops=True)
+    for name, a, r_, p_ in zip(("dq", "dk", "dv"), got, ref, pt):
+        err = (a.float().cpu() - r_.float()).abs().max().item()
+        atol = 2 * (r_.float() + 0.3 - 0.3 - r_.float()).abs().max().item()
+        bound = 3 * (p_.float() - r_.float()).abs().max().item() + atol
+        assert math.isfinite(err) and err <= bound, f"{name}: err {err:.3e} > bound {bound:.3e}"
