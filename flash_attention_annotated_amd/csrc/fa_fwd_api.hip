@@ -566,10 +566,10 @@ bool persist_ok(const fa::KParams &kp) {
 }
 
 // head dims 129 .. 256, plain features: 4 waves x 32 rows around the generated loop FastLoop256 (fa_fwd_kernel_d256.h)
-template <typename T, int DEFF>
+template <typename T, int DEFF, bool SOFTCAP = false>
 int launch_d256(const fa::KParams &kp, hipStream_t stream) {
     constexpr int smem = fa::smem_bytes_d256();
-    auto kernel = fa::fwd_kernel_d256<T, DEFF>;
+    auto kernel = fa::fwd_kernel_d256<T, DEFF, SOFTCAP>;
     static std::atomic<uint64_t> attr_set{0};
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -595,9 +595,14 @@ int dispatch_variant(const fa::KParams &kp, bool softcap, int variant, hipStream
     if constexpr (D == 256) {
         // a V head dim of its own on the wide tile (192 / 128, or q/k <= 64 beside v in (128, 256]) with plain features: the
         // generated-loop kernel, head-dim tile by the larger of the two (fa_fwd_kernel_d256.h reads p.dv for V and O)
-        if (kp.dv != kp.d && kp.chunk == 0 && (variant == 0 || variant == 3) && !softcap && !kp.alibi && !kp.block_table &&
+        if (kp.dv != kp.d && kp.chunk == 0 && (variant == 0 || variant == 3) && !kp.alibi && !kp.block_table &&
             kp.num_splits <= 1 && kp.rp_dropout == 1.f) {
             const int w = std::max(kp.d, kp.dv);
+            if (softcap) {
+                if (w <= 160) return launch_d256<T, 160, true>(kp, stream);
+                if (w <= 192) return launch_d256<T, 192, true>(kp, stream);
+                return launch_d256<T, 256, true>(kp, stream);
+            }
             if (w <= 160) return launch_d256<T, 160>(kp, stream);
             if (w <= 192) return launch_d256<T, 192>(kp, stream);
             return launch_d256<T, 256>(kp, stream);
@@ -615,10 +620,15 @@ int dispatch_variant(const fa::KParams &kp, bool softcap, int variant, hipStream
         else return launch<T, D, 8, false, true>(kp, stream);
     }
     if constexpr (D == 256) {
-        // round 3: the plain problems (dense / varlen, causal / windows, GQA) run the generated-loop kernel; softcap, ALiBi,
+        // round 3: the plain problems (dense / varlen, causal / windows, GQA, softcap) run the generated-loop kernel; ALiBi,
         // paged caches, split-KV and the short-q / explicit shapes keep the compiler-scheduled one
-        if ((variant == 0 || variant == 3) && !softcap && !kp.alibi && !kp.block_table && kp.num_splits <= 1) {
+        if ((variant == 0 || variant == 3) && !kp.alibi && !kp.block_table && kp.num_splits <= 1) {
             // head-dim tiles 160 / 192 / 256 (hopper/tile_size.h:20-45): the zero padding is neither multiplied nor accumulated
+            if (softcap) {  // (round 3: the generated loop caps the scores itself, FastLoop256<T, DEFF, true>)
+                if (kp.d <= 160) return launch_d256<T, 160, true>(kp, stream);
+                if (kp.d <= 192) return launch_d256<T, 192, true>(kp, stream);
+                return launch_d256<T, 256, true>(kp, stream);
+            }
             if (kp.d <= 160) return launch_d256<T, 160>(kp, stream);
             if (kp.d <= 192) return launch_d256<T, 192>(kp, stream);
             return launch_d256<T, 256>(kp, stream);

@@ -17,8 +17,8 @@
 //   * the steady state (runs of half-steps that need no mask) is the generated asm block fa::FastLoop256<T>
 //     (fa_fwd_loop_d256_gen.h, tools/gen_fwd_loop_d256.py); masks, tails and guard trips go through generic_half below, which
 //     shares the LDS images and the pipeline state with it.
-// Features: dense / varlen / seqused / leftpad, causal and sliding windows, GQA.  Softcap, ALiBi, dropout, paged caches and
-// split-KV keep the fwd_kernel<T, 256, 4> instantiations (host policy in fa_fwd_api.hip).
+// Features: dense / varlen / seqused / leftpad, causal and sliding windows, GQA, softcap (SOFTCAP instantiations), a V head dim
+// of its own.  ALiBi, dropout, paged caches and split-KV keep the fwd_kernel<T, 256, 4> instantiations (fa_fwd_api.hip).
 #pragma once
 
 #include "fa_fwd_kernel_w64.h"
@@ -53,7 +53,10 @@ __device__ __forceinline__ void dma_tile_d256(uint32_t lds, u32x4 desc, uint32_t
 
 // DEFF: 256, or 192 / 160 when the head dim is <= 192 / <= 160 -- the k-steps and O blocks of the zero padding are skipped
 // (12 + 12 / 10 + 10 instead of 16 + 16 MFMAs per half-step; the LDS images keep their 512-byte rows)
-template <typename T, int DEFF>
+// SOFTCAP: scores = softcap * tanh(q.k * softmax_scale / softcap) (set_params_fprop csrc/flash_attn/flash_api.cpp:103-117; Gemma-2's
+// head dim 256 + softcap): the generated block caps the fresh scores in place (FastLoop256<T, DEFF, true>), the generic
+// half-step right behind its score product.
+template <typename T, int DEFF, bool SOFTCAP = false>
 __global__ __launch_bounds__(256, 1) void fwd_kernel_d256(const KParams p) {
     constexpr int D = 256;
     constexpr int KS_EFF = DEFF / 16, DB_EFF = DEFF / 32;
@@ -245,6 +248,12 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_d256(const KParams p) {
         if (p.window_left >= 0) need = need || (k0 < wrow + 31 + shift - p.window_left);
         return need;
     };
+    auto cap_scores = [&](f32x16 &s) {  // softcap before the mask, as everywhere (src/mask.h order)
+        if constexpr (SOFTCAP) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s[i] = fast_tanh(s[i] * sc.softcap_pre);
+        }
+    };
     auto mask_scores = [&](int j, f32x16 &s) {
         if (!half_needs_mask(j)) return;
         const int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -330,6 +339,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_d256(const KParams p) {
     bool moved = false, redo = false;
     if (jend > 0) {
         qk_half(0, 1, s);  // half-step 0 = second half of the shifted K tile n_min
+        cap_scores(s);
         mask_scores(0, s);
         softmax(s, pc, alpha, moved);
         moved = false;     // O is still zero
@@ -354,6 +364,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_d256(const KParams p) {
             moved = false;
             if (j + 1 < jend) {
                 qk_half(slot ^ 1, kb, s);
+                cap_scores(s);
                 mask_scores(j + 1, s);
             }
             pv_half(slot, kb, pc);
@@ -396,9 +407,16 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_d256(const KParams p) {
                 uint32_t vtile = (uint32_t)((n_cur + 1) * BLOCK_N * v_rs * 2);
                 int done = 0;
                 uint64_t redo_mask = 0;
+                if constexpr (SOFTCAP) {
+                    float cap2 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sc.softcap_pre * 2.885390081777927f)));
+                    FastLoop256<T, DEFF, true>::run(oa, qf, s, pc, pn, l_run, l_saved, m_run * csc, (uint32_t)kbase, (uint32_t)vbase, koff, voff,
+                                        csc, LIM, kdesc, vdesc, ktile, vtile, (uint32_t)(BLOCK_N * k_rs * 2),
+                                        (uint32_t)(BLOCK_N * v_rs * 2), lds0, lds_wave, (j >> 1) & 1, count, done, redo_mask, cap2);
+                } else {
                 FastLoop256<T, DEFF>::run(oa, qf, s, pc, pn, l_run, l_saved, m_run * csc, (uint32_t)kbase, (uint32_t)vbase, koff, voff,
                                     csc, LIM, kdesc, vdesc, ktile, vtile, (uint32_t)(BLOCK_N * k_rs * 2),
                                     (uint32_t)(BLOCK_N * v_rs * 2), lds0, lds_wave, (j >> 1) & 1, count, done, redo_mask);
+                }
                 j += done;
                 redo = redo_mask != 0;
                 if (done & 1) {  // the fresh P sits in the odd buffer

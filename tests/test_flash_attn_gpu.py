@@ -306,6 +306,35 @@ def test_softcap(causal):
     assert err <= bound, (err, bound)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("d", [160, 192, 256])
+@pytest.mark.parametrize("sq,sk,causal,window", [(1024, 1024, False, (-1, -1)), (777, 1301, True, (-1, -1)),
+                                                 (1024, 1536, False, (300, 0)), (400, 400, False, (-1, -1))])
+def test_softcap_head_dim_tile_256(sq, sk, causal, window, d, dtype):
+    """Softcap on the head-dim-256 tile: the generated block FastLoop256<T, DEFF, true> caps the fresh scores in place (two
+    interleaved tanh chains per score pair) and hands already-capped scores to the generic half-step on a guard trip; scores
+    pushed into the tanh knee like hopper/test_flash_attn.py:139-140; rtol 3 with softcap (:194).  LSE included.  One case
+    per shape also spikes a key late in the sweep so that the guard trips inside a capped block."""
+    fa = _api()
+    torch.manual_seed(sq + sk + d)
+    softcap = 15.0
+    q = torch.randn(2, sq, 4, d, dtype=dtype) * (softcap / 4)
+    k = torch.randn(2, sk, 2, d, dtype=dtype)
+    v = torch.randn(2, sk, 2, d, dtype=dtype)
+    if sk >= 1024:  # after ~12 tiles of scores near -softcap one key reaches +softcap for row 40: partial sums >> 2^THR
+        q[0, 40, 0] = q[0, 40, 0].abs()
+        k[0, : sk - 200, 0] = -k[0, : sk - 200, 0].abs() * 0.5
+        k[0, sk - 150, 0] = k[0, sk - 150, 0].abs() * 2
+    out, lse, _ = fa.flash_attn_func(q.to(DEV), k.to(DEV), v.to(DEV), causal=causal, window_size=window, softcap=softcap,
+                                     return_attn_probs=True)
+    ref_window = (window[0], sk) if (window[0] >= 0 and window[1] < 0) else window
+    out_ref, out_pt, lse_ref = _dense_ref(q, k, v, causal=causal, window_size=ref_window, softcap=softcap)
+    err = (out.float().cpu() - out_ref.float()).abs().max().item()
+    bound = 3 * (out_pt.float() - out_ref.float()).abs().max().item() + 2 * (out_ref + 0.3 - 0.3 - out_ref).abs().max().item()
+    assert err <= bound, (err, bound)
+    _check_lse(lse, lse_ref, tol=5e-3)
+
+
 @pytest.mark.parametrize("causal", [False, True])
 @pytest.mark.parametrize("d", [64, 128])
 @pytest.mark.parametrize("sq,sk", [(1, 147), (113, 203), (128, 217), (512, 512), (1024, 1024)])

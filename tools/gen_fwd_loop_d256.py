@@ -33,6 +33,7 @@ NPAIRS = 8                  # score pairs per 32 x 32 block and lane
 LD = 8                      # LDS-DMA pieces per wave, tile and matrix
 FD = 4                      # LDS fragments are fetched FD MFMAs ahead (every MFMA has a fragment of its own here)
 RING = FD + 1
+SOFTCAP = False             # variant that soft-caps the fresh scores in place (s <- tanh(s * pre)) in front of their softmax
 ABLATE = 0                  # developer-only timing ablations: 1 no LDS-DMA, 2 no guard, 8 no softmax VALU, 16 no barrier
 
 # ---- register map (arch VGPRs) ----
@@ -167,11 +168,32 @@ def gen_half(E, slot, KB, uid):
         if valu:
             if t == 0:
                 E.e("s_nop 7")          # the last score MFMA's result -> its first VALU reader (in the shadow of this MFMA)
+            # SOFTCAP: tanh(x) = 1 - 2 / (exp(2 x) + 1) on the pair's two scores, in place (cap2 = 2 log2(e) softmax_scale / softcap;
+            # fast_tanh of fa_fwd_kernel.h; hopper/utils.h:635-641).  Two interleaved chains: a transcendental's result is never
+            # read by the very next instruction.  The first half (mul, exp, +1, rcp) behind the slice's first MFMA, the rest and the
+            # pair's softmax behind the second.
+            def tanh_a(r0, r1):
+                return [f"v_mul_f32 {v(T0)}, %[cap2], {v(r0)}", f"v_mul_f32 {v(T1)}, %[cap2], {v(r1)}",
+                        f"v_exp_f32 {v(T0)}, {v(T0)}", f"v_exp_f32 {v(T1)}, {v(T1)}",
+                        f"v_add_f32 {v(T0)}, 1.0, {v(T0)}", f"v_add_f32 {v(T1)}, 1.0, {v(T1)}",
+                        f"v_rcp_f32 {v(T0)}, {v(T0)}", f"v_rcp_f32 {v(T1)}, {v(T1)}"]
+            def tanh_b(r0, r1):
+                return [f"v_fma_f32 {v(r0)}, {v(T0)}, -2.0, 1.0", f"v_fma_f32 {v(r1)}, {v(T1)}, -2.0, 1.0"]
             if st == 0:
-                E.e(f"v_fma_f32 {v(t0)}, {v(s0)}, %[csc], -{v(MC)}")
-                E.e(f"v_fma_f32 {v(t1)}, {v(s1)}, %[csc], -{v(MC)}")
-                E.e(f"v_exp_f32 {v(t0)}, {v(t0)}")
+                if SOFTCAP:
+                    for ins in tanh_a(s0, s1):
+                        E.e(ins)
+                else:
+                    E.e(f"v_fma_f32 {v(t0)}, {v(s0)}, %[csc], -{v(MC)}")
+                    E.e(f"v_fma_f32 {v(t1)}, {v(s1)}, %[csc], -{v(MC)}")
+                    E.e(f"v_exp_f32 {v(t0)}, {v(t0)}")
             else:
+                if SOFTCAP:
+                    for ins in tanh_b(s0, s1):
+                        E.e(ins)
+                    E.e(f"v_fma_f32 {v(t0)}, {v(s0)}, %[csc], -{v(MC)}")
+                    E.e(f"v_fma_f32 {v(t1)}, {v(s1)}, %[csc], -{v(MC)}")
+                    E.e(f"v_exp_f32 {v(t0)}, {v(t0)}")
                 E.e(f"v_exp_f32 {v(t1)}, {v(t1)}")
                 if direct:
                     E.e("s_nop 0")      # (one instruction between the second v_exp and the pack that reads it)
@@ -181,6 +203,9 @@ def gen_half(E, slot, KB, uid):
                 for ins in E.cvt(p_nxt + pr, t0, t1):
                     E.e(ins)
                 for pr2 in prs[1:]:     # (DEFF 192 / 160: 8 pairs over 6 / 5 slices)
+                    if SOFTCAP:
+                        for ins in tanh_a(S + 2 * pr2, S + 2 * pr2 + 1) + tanh_b(S + 2 * pr2, S + 2 * pr2 + 1):
+                            E.e(ins)
                     E.e(f"v_fma_f32 {v(T0)}, {v(S + 2 * pr2)}, %[csc], -{v(MC)}")
                     E.e(f"v_fma_f32 {v(T1)}, {v(S + 2 * pr2 + 1)}, %[csc], -{v(MC)}")
                     E.e(f"v_exp_f32 {v(T0)}, {v(T0)}")
@@ -260,16 +285,18 @@ HEADER = '''// GENERATED by tools/gen_fwd_loop_d256.py -- do not edit; regenerat
 namespace fa {
 
 // DEFF: head dims contracted / produced (256, or 192 / 160: the k-steps and O blocks of the zero padding are skipped)
-template <typename T, int DEFF> struct FastLoop256;
+// SOFTCAP: the fresh scores are soft-capped in place before their softmax (cap2 = 2 log2(e) softmax_scale / softcap); on a guard
+// trip the scores the caller redoes P from are already capped.
+template <typename T, int DEFF, bool SOFTCAP = false> struct FastLoop256;
 '''
 
-FUNC = '''template <> struct FastLoop256<%(T)s, %(DEFF)d> {
+FUNC = '''template <> struct FastLoop256<%(T)s, %(DEFF)d, %(SC)s> {
     static __device__ __forceinline__ void run(f32x16 (&oa)[8], u32x4 (&q)[16], f32x16 &s, u32x4 (&peven)[2], u32x4 (&podd)[2],
                                                float &l, float &l_saved, float mc, uint32_t kbase, uint32_t vbase,
                                                const uint32_t (&koff)[8], const uint32_t (&voff)[8], float csc, float lim,
                                                u32x4 kdesc, u32x4 vdesc, uint32_t ktile, uint32_t vtile, uint32_t kstep,
                                                uint32_t vstep, uint32_t lds0, uint32_t lds_wave, int slot0, int &count,
-                                               int &done, uint64_t &redo) {
+                                               int &done, uint64_t &redo%(caparg)s) {
         uint32_t m0save;
         const uint32_t lds0v = lds0 + %(vregion)d;
         asm volatile(
@@ -282,7 +309,7 @@ FUNC = '''template <> struct FastLoop256<%(T)s, %(DEFF)d> {
             : "{v%(MC)d}"(mc), "{v%(KBASE)d}"(kbase), "{v%(VBASE)d}"(vbase),
               %(offs)s,
               [csc] "s"(csc), [lim] "s"(lim), [kstep] "s"(kstep), [vstep] "s"(vstep), [kdesc] "s"(kdesc), [vdesc] "s"(vdesc),
-              [lds0] "s"(lds0), [lds0v] "s"(lds0v), [lds_wave] "s"(lds_wave), [slot0] "s"(slot0)
+              [lds0] "s"(lds0), [lds0v] "s"(lds0v), [lds_wave] "s"(lds_wave), [slot0] "s"(slot0)%(capin)s
             : "memory", "vcc", "scc"%(clobbers)s);
     }
 };
@@ -308,13 +335,16 @@ def main():
     offs = join([f'"{{v{KOFF + i}}}"(koff[{i}])' for i in range(8)] + [f'"{{v{VOFF + i}}}"(voff[{i}])' for i in range(8)])
     bound = set(range(0, 32)) | set(range(KOFF, KOFF + 16)) | {MC, LA, LAS, KBASE, VBASE}
     clob = "".join(f', "v{i}"' for i in range(LAST + 1) if i not in bound)
-    global DEFF, KSTEPS, NSTEP
-    for deff in (256, 192, 160):
-        DEFF, KSTEPS, NSTEP = deff, deff // 16, 2 * (deff // 32)
-        for T, mf, cvt in (("__bf16", "v_mfma_f32_32x32x16_bf16", cvt_bf16), ("_Float16", "v_mfma_f32_32x32x16_f16", cvt_f16)):
-            text += "\n" + FUNC % {"T": T, "DEFF": deff, "body": render(gen_block(mf, cvt)), "accs": accs, "offs": offs,
-                                   "clobbers": clob, "vregion": 2 * TILE, "LA": LA, "LAS": LAS, "MC": MC, "KBASE": KBASE,
-                                   "VBASE": VBASE}
+    global DEFF, KSTEPS, NSTEP, SOFTCAP
+    for softcap in (False, True):
+        SOFTCAP = softcap
+        for deff in (256, 192, 160):
+            DEFF, KSTEPS, NSTEP = deff, deff // 16, 2 * (deff // 32)
+            for T, mf, cvt in (("__bf16", "v_mfma_f32_32x32x16_bf16", cvt_bf16), ("_Float16", "v_mfma_f32_32x32x16_f16", cvt_f16)):
+                text += "\n" + FUNC % {"T": T, "DEFF": deff, "body": render(gen_block(mf, cvt)), "accs": accs, "offs": offs,
+                                       "clobbers": clob, "vregion": 2 * TILE, "LA": LA, "LAS": LAS, "MC": MC, "KBASE": KBASE,
+                                       "VBASE": VBASE, "SC": "true" if softcap else "false",
+                                       "caparg": ", float cap2" if softcap else "", "capin": ', [cap2] "s"(cap2)' if softcap else ""}
     text += "\n}  // namespace fa\n"
     if "--check" in sys.argv:
         sys.exit(0 if os.path.exists(path) and open(path).read() == text else 1)
