@@ -338,7 +338,8 @@ def main():
     global DEFF, KSTEPS, NSTEP, SOFTCAP
     for softcap in (False, True):
         SOFTCAP = softcap
-        for deff in (256, 192, 160):
+        # (DEFF = 128 exists for softcap only: head dims 97..128 with softcap run this kernel shape, fa_fwd_api.hip)
+        for deff in ((256, 192, 160, 128) if softcap else (256, 192, 160)):
             DEFF, KSTEPS, NSTEP = deff, deff // 16, 2 * (deff // 32)
             for T, mf, cvt in (("__bf16", "v_mfma_f32_32x32x16_bf16", cvt_bf16), ("_Float16", "v_mfma_f32_32x32x16_f16", cvt_f16)):
                 text += "\n" + FUNC % {"T": T, "DEFF": deff, "body": render(gen_block(mf, cvt)), "accs": accs, "offs": offs,
