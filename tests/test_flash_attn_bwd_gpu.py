@@ -118,6 +118,41 @@ def test_head_dims_grads(d):
     _check_grads(got, ref, pt, f"d={d}")
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("kw", [dict(), dict(causal=True), dict(window_size=(200, 40)), dict(causal=True, softcap=20.0),
+                                dict(alibi=True, causal=True), dict(causal=True, dropout_p=0.17)],
+                         ids=["plain", "causal", "window", "softcap", "alibi", "dropout"])
+@pytest.mark.parametrize("d", [136, 160, 192, 256])
+def test_wide_head_dim_grads(d, kw, dtype):
+    """Head dims 129 .. 256: dV and dK come from a launch each (bwd_dkdv_kernel PART 1 / 2 -- one pinned accumulator set per
+    sweep), head dims <= 160 / <= 192 on the instantiations that skip the zero padding; sweeps of several key blocks and query
+    tiles, GQA 4 / 2, sq != sk.  Dropout: the keep-mask is read back from the sign of S_dmask (tests/test_dropout_gpu.py)."""
+    fa = _api()
+    kw = dict(kw)
+    torch.manual_seed(d)
+    b, sq, sk, h, hk = 2, 520, 700, 4, 2
+    q = torch.randn(b, sq, h, d, dtype=dtype) * (5.0 if kw.get("softcap") else 1.0)
+    k = torch.randn(b, sk, hk, d, dtype=dtype)
+    v = torch.randn(b, sk, hk, d, dtype=dtype)
+    g = torch.randn(b, sq, h, d, dtype=dtype)
+    okw = {k_: v_ for k_, v_ in kw.items() if k_ not in ("alibi", "dropout_p")}
+    if kw.pop("alibi", False):
+        slopes = torch.rand(b, h) * 0.3
+        kw["alibi_slopes"] = slopes.to(DEV)
+        okw["attn_bias"] = oracle.attn_bias_from_alibi_slopes(slopes, sq, sk, causal=okw.get("causal", False))
+    p = kw.get("dropout_p", 0.0)
+    if p > 0:
+        ql, kl, vl = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
+        out, _, sd = fa.flash_attn_func(ql, kl, vl, return_attn_probs=True, **kw)
+        got = torch.autograd.grad(out, (ql, kl, vl), g.to(DEV))
+        keep = ~(torch.signbit(sd[:, :, :sq, :sk].float().cpu()))
+        okw.update(dropout_p=p, dropout_mask=keep)
+    else:
+        _, got = _hip_grads(fa.flash_attn_func, q, k, v, g, **kw)
+    ref, pt = _oracle_grads(q, k, v, g, **okw)
+    _check_grads(got, ref, pt, f"d={d} {kw}")
+
+
 @pytest.mark.parametrize("window", [(64, 0), (16, 16), (0, 32), (-1, 17)])
 @pytest.mark.parametrize("sq,sk", [(113, 203), (300, 300), (400, 150)])
 def test_local_window_grads(sq, sk, window):
