@@ -22,14 +22,21 @@ for w in c2 c3 c4 c5; do
   python tools/pmc_sum.py $R/pmc_a_$w $R/pmc_b_$w $R/pmc_c_$w $R/pmc_d_$w > $R/pmc_summary_$w.txt
   echo "pmc $w done"
 done
-FA_FWD_LIB=tools/bin/libfa_cycles.so timeout -k 10 100 python tools/loop_cycles.py 2>&1 | grep -v amdgpu.ids | head -3 > $R/loop_cycles.txt
-timeout -k 10 200 ./tools/bin/mfma_ceiling > $R/ceiling.txt 2>&1
+# (developer builds, tools/README.md; skipped when they were not built in this container)
+if [ -f tools/bin/libfa_cycles.so ]; then FA_FWD_LIB=tools/bin/libfa_cycles.so timeout -k 10 100 python tools/loop_cycles.py 2>&1 | grep -v amdgpu.ids | head -3 > $R/loop_cycles.txt || true; fi
+if [ -x tools/bin/mfma_ceiling ]; then timeout -k 10 200 ./tools/bin/mfma_ceiling > $R/ceiling.txt 2>&1 || true; fi
 timeout -k 10 300 python tools/fwd_grid.py 0 2>&1 | grep -v amdgpu > $R/fwd_grid.txt
 timeout -k 10 300 python tools/hdim_bench.py 2>&1 | grep -v amdgpu > $R/hdim.txt
 timeout -k 10 300 python tools/bwd_hdim_bench.py 2>&1 | grep -v amdgpu > $R/bwd_hdim.txt
 timeout -k 10 300 python tools/varlen_short_bench.py 2>&1 | grep -v amdgpu > $R/varlen_short.txt
 timeout -k 10 300 python tools/window_bench.py 2>&1 | grep -v amdgpu > $R/window_bench.txt
 timeout -k 10 300 python tools/dropout_bench.py 2>&1 | grep -v amdgpu > $R/dropout.txt
+timeout -k 10 300 python tools/feature_survey.py 2>&1 | grep -v amdgpu > $R/feature_survey.txt
+timeout -k 10 300 python tools/inference_survey.py 2>&1 | grep -v amdgpu > $R/inference_survey.txt
+timeout -k 10 300 python tools/dv_chunk_bench.py 2>&1 | grep -v amdgpu > $R/dv_chunk.txt
+timeout -k 10 300 python tools/persist_sweep.py 2>&1 | grep -v amdgpu > $R/persist_sweep.txt || true
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/kt_bwd_d256 -o bwd_d256 -- python3 tools/bwd_hdim_bench.py 256 > $R/kt_bwd_d256.txt 2> $R/kt_bwd_d256.err || true
+echo "grids done"
 python - <<PY
 import json
 for w in ("c2", "c3", "c4", "c5", "c2_bwd", "c3_bwd", "decode"):
