@@ -639,10 +639,12 @@ int dispatch_variant(const fa::KParams &kp, bool softcap, int variant, hipStream
         if (softcap) return launch<T, D, 4, true>(kp, stream);
         return launch<T, D, 4, false>(kp, stream);
     } else {
+        // variant 4 (internal, fa_fwd): softcap at head dims <= 128 with plain features on the head-dim-256 kernel's shape (one
+        // 32-row q-block per wave, FastLoop256<T, DEFF <= 128, true>): the 256-row kernel has no generated loop under softcap
         if constexpr (D == 128) {
-            // variant 4 (internal, fa_fwd): softcap at head dims 65..128 with plain features on the head-dim-256 kernel's shape
-            // (one 32-row q-block per wave, FastLoop256<T, 128, true>): the 256-row kernel has no generated loop under softcap
-            if (variant == 4) return launch_d256<T, 128, true>(kp, stream);
+            if (variant == 4) return kp.d <= 96 ? launch_d256<T, 96, true>(kp, stream) : launch_d256<T, 128, true>(kp, stream);
+        } else {
+            if (variant == 4) return launch_d256<T, 64, true>(kp, stream);
         }
         if (variant == 0 || variant == 3) {
             if (softcap) return launch_w64<T, D, true>(kp, stream);
@@ -922,10 +924,10 @@ int fa_fwd(const fa_fwd_params *p, void *stream_) {
     }
     int variant = effective_variant(p);
     int block_m = block_m_of(variant, wide_dim(p));
-    {   // softcap at head dims 65..128 (measured b4 s4096 h16 d128: 471 TFLOP/s through the C++ loop of the 256-row kernel):
-        // the generated loop that caps scores exists for the 32-row-per-wave shape only -> its DEFF = 128 instantiation
+    {   // softcap at head dims <= 128 (measured b4 s4096: d128 471, d64 322 TFLOP/s through the C++ loop of the 256-row kernel):
+        // the generated loop that caps scores exists for the 32-row-per-wave shape only -> its DEFF = 64 / 96 / 128 instantiations
         const bool nothing_ = p->seqlen_q == 0 || p->seqlen_k == 0 || (p->cu_seqlens_q && p->total_q == 0);
-        if (p->softcap > 0.f && variant == 0 && head_dim_tile(p->d) == 128 && p->d > 64 && !generic_only(p) && !p->alibi_slopes &&
+        if (p->softcap > 0.f && variant == 0 && p->d <= 128 && !generic_only(p) && !p->alibi_slopes &&
             !p->block_table && p->p_dropout == 0.f && !nothing_ && split_plan(p, variant).splits <= 1 &&
             !(p->dtype == FA_DTYPE_FP8_E4M3 && fp8_native(p))) {
             variant = 4;

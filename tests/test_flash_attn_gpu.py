@@ -307,15 +307,16 @@ def test_softcap(causal):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("d", [72, 96, 128, 160, 192, 256])
+@pytest.mark.parametrize("d", [40, 64, 72, 96, 128, 160, 192, 256])
 @pytest.mark.parametrize("sq,sk,causal,window", [(1024, 1024, False, (-1, -1)), (777, 1301, True, (-1, -1)),
-                                                 (1024, 1536, False, (300, 0)), (400, 400, False, (-1, -1))])
+                                                 (1024, 1536, False, (300, 0)), (400, 400, False, (-1, -1)), (3000, 3000, True, (-1, -1))])
 def test_softcap_head_dim_tile_256(sq, sk, causal, window, d, dtype):
     """Softcap on the head-dim-256 tile: the generated block FastLoop256<T, DEFF, true> caps the fresh scores in place (two
     interleaved tanh chains per score pair) and hands already-capped scores to the generic half-step on a guard trip; scores
     pushed into the tanh knee like hopper/test_flash_attn.py:139-140; rtol 3 with softcap (:194).  LSE included.  One case
-    per shape also spikes a key late in the sweep so that the guard trips inside a capped block.  Head dims 65 .. 128 with softcap
-    take the same kernel shape (DEFF = 128 instantiation, fa_fwd_api.hip variant 4)."""
+    per shape also spikes a key late in the sweep so that the guard trips inside a capped block.  Head dims <= 128 with softcap
+    take the same kernel shape (DEFF = 64 / 96 / 128 instantiations, fa_fwd_api.hip variant 4; short causal sweeps at head dim
+    <= 64 keep the 4-wave x 32-row compiler-scheduled shape)."""
     fa = _api()
     torch.manual_seed(sq + sk + d)
     softcap = 15.0

@@ -127,16 +127,24 @@ def gen_half(E, slot, KB, uid):
             E.ds_k(kf(nks), nks, nk_off, tag_of(i))
 
     E.e(f"; ---- slot {slot} half-step KB={KB}: phase 1 (scores of the next half-step)")
+    def pieces_of(i, n):
+        """LDS-DMA pieces issued in slice i of n: one per slice while n >= LD, otherwise the LD pieces dealt in order over the n
+        slices (DEFF < 128: fewer MFMA slices than pieces); a slice's pieces never straddle an M0 group of four"""
+        ps = [i] if (n >= LD and i < LD) else ([] if n >= LD else [p for p in range(LD) if p * n // LD == i])
+        assert not ps or ps[0] // 4 == ps[-1] // 4
+        return ps
     for ks in range(KSTEPS):
-        if KB == 0 and ks % 4 == 0 and ks < LD:
-            E.e(f"s_add_u32 m0, %[lds_wave], {kdst + 1024 * ks}")
+        kp_ = pieces_of(ks, KSTEPS) if KB == 0 else []
+        if kp_ and kp_[0] % 4 == 0:
+            E.e(f"s_add_u32 m0, %[lds_wave], {kdst + 1024 * kp_[0]}")
         E.wait_for(tag_of(ks))            # (a no-op but for the half-step's first fragment: the previous MFMA's shadow waited)
         c = "0" if ks == 0 else v(S, 16)
         E.e(f"{mf} {v(S, 16)}, {v(kf(ks), 4)}, %[q{ks}], {c}")
         if not (KB == 1 and ks + FD >= KSTEPS + NSTEP):
             fetch(ks + FD)
-        if KB == 0 and ks < LD and not (ABLATE & 1):
-            E.e(f"buffer_load_dwordx4 {v(KOFF + ks)}, %[kdesc], %[ktile] offen offset:{1024 * (ks % 4)} lds")
+        if not (ABLATE & 1):
+            for pc in kp_:
+                E.e(f"buffer_load_dwordx4 {v(KOFF + pc)}, %[kdesc], %[ktile] offen offset:{1024 * (pc % 4)} lds")
         E.wait_for(tag_of(ks + 1))
     if KB == 0:
         E.e("s_add_u32 %[ktile], %[ktile], %[kstep]")
@@ -156,13 +164,15 @@ def gen_half(E, slot, KB, uid):
             E.lds_q = []
             if not (ABLATE & 16):
                 E.e("s_barrier")
-        if KB == 0 and t % 4 == 0 and t < LD:
-            E.e(f"s_add_u32 m0, %[lds_wave], {vdst + 1024 * t}")
+        vp_ = pieces_of(t, NSTEP) if KB == 0 else []
+        if vp_ and vp_[0] % 4 == 0:
+            E.e(f"s_add_u32 m0, %[lds_wave], {vdst + 1024 * vp_[0]}")
         E.wait_for(tag_of(KSTEPS + t))
         E.e(f"{mf} %[oa{db}], {v(vf(t), 4)}, {v(p_cur + 4 * st, 4)}, %[oa{db}]")
         fetch(KSTEPS + t + FD)
-        if KB == 0 and t < LD and not (ABLATE & 1):
-            E.e(f"buffer_load_dwordx4 {v(VOFF + t)}, %[vdesc], %[vtile] offen offset:{1024 * (t % 4)} lds")
+        if not (ABLATE & 1):
+            for pc in vp_:
+                E.e(f"buffer_load_dwordx4 {v(VOFF + pc)}, %[vdesc], %[vtile] offen offset:{1024 * (pc % 4)} lds")
         if not (KB == 1 and t == NSTEP - 1):
             E.wait_for(tag_of(KSTEPS + t + 1))
         if valu:
@@ -338,8 +348,8 @@ def main():
     global DEFF, KSTEPS, NSTEP, SOFTCAP
     for softcap in (False, True):
         SOFTCAP = softcap
-        # (DEFF = 128 exists for softcap only: head dims 97..128 with softcap run this kernel shape, fa_fwd_api.hip)
-        for deff in ((256, 192, 160, 128) if softcap else (256, 192, 160)):
+        # (DEFF <= 128 exists for softcap only: head dims <= 128 with softcap run this kernel shape, fa_fwd_api.hip variant 4)
+        for deff in ((256, 192, 160, 128, 96, 64) if softcap else (256, 192, 160)):
             DEFF, KSTEPS, NSTEP = deff, deff // 16, 2 * (deff // 32)
             for T, mf, cvt in (("__bf16", "v_mfma_f32_32x32x16_bf16", cvt_bf16), ("_Float16", "v_mfma_f32_32x32x16_f16", cvt_f16)):
                 text += "\n" + FUNC % {"T": T, "DEFF": deff, "body": render(gen_block(mf, cvt)), "accs": accs, "offs": offs,
