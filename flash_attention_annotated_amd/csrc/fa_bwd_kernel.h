@@ -380,14 +380,14 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_kernel(const BParams p) {
 
     // ---- Q / dO tile staging: rows clamped into the sequence (clamped rows are masked).  LDS-DMA
     //      (global_load_lds_dwordx4, no staging registers, swizzle applied on the source side: see
-    //      fa_fwd_kernel_w64.h) where a tile is <= 4 pieces per wave; register staged for D = 256. ------------------
-    constexpr bool DMA = LD_PER_THREAD <= 4;
+    //      fa_fwd_kernel_w64.h), 2 / 4 / 8 pieces per wave at head-dim tiles 64 / 128 / 256. ------------------------------
+    constexpr bool DMA = LD_PER_THREAD <= 8;   // (round 3: the 256 tile's 8 pieces per wave go by LDS-DMA too)
     constexpr int NSTAGE = DMA ? 1 : LD_PER_THREAD;
     u32x4 qreg[NSTAGE], greg[NSTAGE];
     float stat_reg = 0.f;
     auto tile_head = [&](int it) { return kv_head * p.h_ratio + it / num_m; };
     auto tile_row0 = [&](int it) { return (m_min + it % num_m) * BM; };
-    int dma_row[LD_PER_THREAD], dma_col[LD_PER_THREAD];
+    int dma_row[LD_PER_THREAD], dma_col[LD_PER_THREAD], dma_colv[LD_PER_THREAD];
     uint32_t q_off[LD_PER_THREAD], g_off[LD_PER_THREAD];  // byte offsets of this lane's chunks inside an in-range tile
     const int q_rs = (int)p.q_row_stride, g_rs = (int)p.do_row_stride;  // host guarantees < 2^24
     if constexpr (DMA) {
@@ -400,8 +400,10 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_kernel(const BParams p) {
             else ch = (slot % CH_PER_ROW) ^ (((row & 3) << 2) | ((row >> 2) & 3));
             dma_row[i] = row;
             dma_col[i] = (ch * 8 < p.d) ? ch * 8 : 0;
+            // dO has d_v columns (= d unless the FA3 headdim_v differs: wide tile only, no second table elsewhere)
+            dma_colv[i] = D == 256 ? ((ch * 8 < p.d_v) ? ch * 8 : 0) : dma_col[i];
             q_off[i] = (uint32_t)(row * q_rs + dma_col[i]) * 2u;
-            g_off[i] = (uint32_t)(row * g_rs + dma_col[i]) * 2u;
+            g_off[i] = (uint32_t)(row * g_rs + dma_colv[i]) * 2u;
         }
     }
     const uint32_t lds_wave = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem + wave * (LD_PER_THREAD * 1024);
@@ -420,7 +422,7 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_kernel(const BParams p) {
                 for (int i = 0; i < LD_PER_THREAD; ++i) {
                     const int rel = min(row0 + dma_row[i], sq - 1) - row0;
                     qo[i] = (uint32_t)(rel * q_rs + dma_col[i]) * 2u;
-                    go[i] = (uint32_t)(rel * g_rs + dma_col[i]) * 2u;
+                    go[i] = (uint32_t)(rel * g_rs + dma_colv[i]) * 2u;
                 }
                 lds_dma<LD_PER_THREAD>(lds_wave + buf * TILE_BYTES, qt, qo);
                 lds_dma<LD_PER_THREAD>(lds_wave + (2 + buf) * TILE_BYTES, gt, go);
@@ -834,11 +836,11 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_kernel(const BParams p) {
         for (int i = 0; i < NB * DBLOCKS; ++i) Mfma<T>::o_zero(dq_acc[i], z4);
     }
 
-    // ---- K/V staging: clamped rows; LDS-DMA where a tile is <= 4 pieces per wave, register staged for D = 256 ------
-    constexpr bool DMA = LD_PER_THREAD <= 4;
+    // ---- K/V staging: clamped rows, by LDS-DMA (2 / 4 / 8 pieces per wave at head-dim tiles 64 / 128 / 256) ----------
+    constexpr bool DMA = LD_PER_THREAD <= 8;   // (round 3: the 256 tile's 8 pieces per wave go by LDS-DMA too)
     constexpr int NSTAGE = DMA ? 1 : LD_PER_THREAD;
     u32x4 kreg[NSTAGE], vreg[NSTAGE];
-    int dma_row[LD_PER_THREAD], dma_col[LD_PER_THREAD];
+    int dma_row[LD_PER_THREAD], dma_col[LD_PER_THREAD], dma_colv[LD_PER_THREAD];
     uint32_t k_off[LD_PER_THREAD], v_off[LD_PER_THREAD];
     const int k_rs = (int)p.k_row_stride, v_rs = (int)p.v_row_stride;  // host guarantees < 2^24
     if constexpr (DMA) {
@@ -851,8 +853,9 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_kernel(const BParams p) {
             else ch = (slot % CH_PER_ROW) ^ (((row & 3) << 2) | ((row >> 2) & 3));
             dma_row[i] = row;
             dma_col[i] = (ch * 8 < p.d) ? ch * 8 : 0;
+            dma_colv[i] = D == 256 ? ((ch * 8 < p.d_v) ? ch * 8 : 0) : dma_col[i];
             k_off[i] = (uint32_t)(row * k_rs + dma_col[i]) * 2u;
-            v_off[i] = (uint32_t)(row * v_rs + dma_col[i]) * 2u;
+            v_off[i] = (uint32_t)(row * v_rs + dma_colv[i]) * 2u;
         }
     }
     const uint32_t lds_wave = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem + wave * (LD_PER_THREAD * 1024);
@@ -869,7 +872,7 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_kernel(const BParams p) {
                 for (int i = 0; i < LD_PER_THREAD; ++i) {
                     const int rel = min(k0 + dma_row[i], sk - 1) - k0;
                     ko[i] = (uint32_t)(rel * k_rs + dma_col[i]) * 2u;
-                    vo[i] = (uint32_t)(rel * v_rs + dma_col[i]) * 2u;
+                    vo[i] = (uint32_t)(rel * v_rs + dma_colv[i]) * 2u;
                 }
                 lds_dma<LD_PER_THREAD>(lds_wave + buf * TILE_BYTES, kt, ko);
                 lds_dma<LD_PER_THREAD>(lds_wave + (NBUF + buf) * TILE_BYTES, vt, vo);

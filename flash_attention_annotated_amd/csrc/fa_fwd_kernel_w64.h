@@ -276,8 +276,24 @@ template <> struct Fused<_Float16> {
 template <int N>
 __device__ __forceinline__ void lds_dma(uint32_t lds, const void *base, const uint32_t (&off)[N]) {
     uint32_t keep;
-    static_assert(N == 2 || N == 4, "pieces per wave and tile");
-    if constexpr (N == 4) {
+    static_assert(N == 2 || N == 4 || N == 8, "pieces per wave and tile");
+    if constexpr (N == 8) {  // (head-dim tile 256: 512-byte rows, the backward's Q / dO / K / V tiles)
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %1\n\t"
+            "s_add_u32 m0, %2, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %1\n\t"
+            "s_add_u32 m0, %2, 2048\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %6, %1\n\t"
+            "s_add_u32 m0, %2, 3072\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %7, %1\n\t"
+            "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %8, %1\n\t"
+            "s_add_u32 m0, %3, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %9, %1\n\t"
+            "s_add_u32 m0, %3, 2048\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %10, %1\n\t"
+            "s_add_u32 m0, %3, 3072\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %11, %1\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "s"(base), "s"(lds), "s"(lds + 4096), "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "v"(off[4]), "v"(off[5]),
+              "v"(off[6]), "v"(off[7])
+            : "memory", "scc");
+    } else if constexpr (N == 4) {
         asm volatile(
             "s_mov_b32 %0, m0\n\t"
             "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %6, %1\n\t"
