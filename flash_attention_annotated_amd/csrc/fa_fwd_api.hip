@@ -566,10 +566,10 @@ bool persist_ok(const fa::KParams &kp) {
 }
 
 // head dims 129 .. 256, plain features: 4 waves x 32 rows around the generated loop FastLoop256 (fa_fwd_kernel_d256.h)
-template <typename T, int DEFF, bool SOFTCAP = false>
+template <typename T, int DEFF, bool SOFTCAP = false, bool ALIBI = false>
 int launch_d256(const fa::KParams &kp, hipStream_t stream) {
     constexpr int smem = fa::smem_bytes_d256();
-    auto kernel = fa::fwd_kernel_d256<T, DEFF, SOFTCAP>;
+    auto kernel = fa::fwd_kernel_d256<T, DEFF, SOFTCAP, ALIBI>;
     static std::atomic<uint64_t> attr_set{0};
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -586,27 +586,33 @@ int launch_d256(const fa::KParams &kp, hipStream_t stream) {
     return FA_OK;
 }
 
+// the 32-row-per-wave kernel (fa_fwd_kernel_d256.h) at head-dim tile W (64 .. 256), plain / softcap / ALiBi form
+template <typename T, int W>
+int launch_d256_form(const fa::KParams &kp, bool softcap, hipStream_t stream) {
+    if (softcap) return launch_d256<T, W, true, false>(kp, stream);
+    if (kp.alibi) return launch_d256<T, W, false, true>(kp, stream);
+    if constexpr (W >= 160) return launch_d256<T, W>(kp, stream);
+    else return FA_ERR_UNSUPPORTED;   // (head dims <= 128 without softcap / ALiBi run the 256-row kernel: never dispatched here)
+}
+template <typename T>
+int launch_d256_wide(const fa::KParams &kp, int w, bool softcap, hipStream_t stream) {
+    if (w <= 160) return launch_d256_form<T, 160>(kp, softcap, stream);
+    if (w <= 192) return launch_d256_form<T, 192>(kp, softcap, stream);
+    return launch_d256_form<T, 256>(kp, softcap, stream);
+}
+
 template <typename T, int D>
 int dispatch_variant(const fa::KParams &kp, bool softcap, int variant, hipStream_t stream) {
     // variant 0/3: 4 waves x 64 rows, one wave per SIMD, software-pipelined (fa_fwd_kernel_w64.h) -- the default
     // variant 1  : 8 waves x 32 rows (BLOCK_M 256), two waves per SIMD (fa_fwd_kernel.h)
     // variant 2  : 4 waves x 32 rows (BLOCK_M 128)
     // D = 256 does not fit the w64 register budget (O alone would be 256 registers): 4 waves x 32 rows.
+    const bool d256_ok = (variant == 0 || variant == 3) && !(softcap && kp.alibi) && !kp.block_table && kp.num_splits <= 1 &&
+                         kp.rp_dropout == 1.f && kp.chunk == 0;
     if constexpr (D == 256) {
         // a V head dim of its own on the wide tile (192 / 128, or q/k <= 64 beside v in (128, 256]) with plain features: the
         // generated-loop kernel, head-dim tile by the larger of the two (fa_fwd_kernel_d256.h reads p.dv for V and O)
-        if (kp.dv != kp.d && kp.chunk == 0 && (variant == 0 || variant == 3) && !kp.alibi && !kp.block_table &&
-            kp.num_splits <= 1 && kp.rp_dropout == 1.f) {
-            const int w = std::max(kp.d, kp.dv);
-            if (softcap) {
-                if (w <= 160) return launch_d256<T, 160, true>(kp, stream);
-                if (w <= 192) return launch_d256<T, 192, true>(kp, stream);
-                return launch_d256<T, 256, true>(kp, stream);
-            }
-            if (w <= 160) return launch_d256<T, 160>(kp, stream);
-            if (w <= 192) return launch_d256<T, 192>(kp, stream);
-            return launch_d256<T, 256>(kp, stream);
-        }
+        if (kp.dv != kp.d && d256_ok) return launch_d256_wide<T>(kp, std::max(kp.d, kp.dv), softcap, stream);
     }
     if (kp.chunk > 0 || kp.dv != kp.d) {
         // attention_chunk / a V head dim of its own (FA3 surface, ABI v12): the EXTRA instantiations of the compiler-scheduled
@@ -622,29 +628,22 @@ int dispatch_variant(const fa::KParams &kp, bool softcap, int variant, hipStream
     if constexpr (D == 256) {
         // round 3: the plain problems (dense / varlen, causal / windows, GQA, softcap) run the generated-loop kernel; ALiBi,
         // paged caches, split-KV and the short-q / explicit shapes keep the compiler-scheduled one
-        if ((variant == 0 || variant == 3) && !kp.alibi && !kp.block_table && kp.num_splits <= 1) {
-            // head-dim tiles 160 / 192 / 256 (hopper/tile_size.h:20-45): the zero padding is neither multiplied nor accumulated
-            if (softcap) {  // (round 3: the generated loop caps the scores itself, FastLoop256<T, DEFF, true>)
-                if (kp.d <= 160) return launch_d256<T, 160, true>(kp, stream);
-                if (kp.d <= 192) return launch_d256<T, 192, true>(kp, stream);
-                return launch_d256<T, 256, true>(kp, stream);
-            }
-            if (kp.d <= 160) return launch_d256<T, 160>(kp, stream);
-            if (kp.d <= 192) return launch_d256<T, 192>(kp, stream);
-            return launch_d256<T, 256>(kp, stream);
-        }
+        // head-dim tiles 160 / 192 / 256 (hopper/tile_size.h:20-45): the zero padding is neither multiplied nor accumulated;
+        // softcap or ALiBi: the forms of the generated loop that cap / bias the fresh scores themselves (round 3)
+        if (d256_ok) return launch_d256_wide<T>(kp, kp.d, softcap, stream);
         // (a DEFF = 192 instantiation -- 12 + 12 instead of 16 + 16 MFMAs per 32-key block -- was measured at exactly the
         //  per-workgroup time of the 256 one, tools/hdim_bench.py: this shape is bound by its register-staged K/V rows, which
         //  stay 512 B wide, not by the matrix pipe; head dims 129..192 therefore keep the 256 instantiation)
         if (softcap) return launch<T, D, 4, true>(kp, stream);
         return launch<T, D, 4, false>(kp, stream);
     } else {
-        // variant 4 (internal, fa_fwd): softcap at head dims <= 128 with plain features on the head-dim-256 kernel's shape (one
-        // 32-row q-block per wave, FastLoop256<T, DEFF <= 128, true>): the 256-row kernel has no generated loop under softcap
+        // variant 4 (internal, fa_fwd): softcap or ALiBi at head dims <= 128 with otherwise plain features on the head-dim-256
+        // kernel's shape (one 32-row q-block per wave, FastLoop256<T, DEFF <= 128, ...>): the 256-row kernel has no generated
+        // loop under either
         if constexpr (D == 128) {
-            if (variant == 4) return kp.d <= 96 ? launch_d256<T, 96, true>(kp, stream) : launch_d256<T, 128, true>(kp, stream);
+            if (variant == 4) return kp.d <= 96 ? launch_d256_form<T, 96>(kp, softcap, stream) : launch_d256_form<T, 128>(kp, softcap, stream);
         } else {
-            if (variant == 4) return launch_d256<T, 64, true>(kp, stream);
+            if (variant == 4) return launch_d256_form<T, 64>(kp, softcap, stream);
         }
         if (variant == 0 || variant == 3) {
             if (softcap) return launch_w64<T, D, true>(kp, stream);
@@ -924,10 +923,11 @@ int fa_fwd(const fa_fwd_params *p, void *stream_) {
     }
     int variant = effective_variant(p);
     int block_m = block_m_of(variant, wide_dim(p));
-    {   // softcap at head dims <= 128 (measured b4 s4096: d128 471, d64 322 TFLOP/s through the C++ loop of the 256-row kernel):
-        // the generated loop that caps scores exists for the 32-row-per-wave shape only -> its DEFF = 64 / 96 / 128 instantiations
+    {   // softcap or ALiBi at head dims <= 128 (measured b4 s4096: softcap d128 471, d64 322, ALiBi 231 / 182 TFLOP/s through the C++
+        // paths of the 256-row kernel): the generated loops that cap / bias scores exist for the 32-row-per-wave shape only ->
+        // its DEFF = 64 / 96 / 128 instantiations
         const bool nothing_ = p->seqlen_q == 0 || p->seqlen_k == 0 || (p->cu_seqlens_q && p->total_q == 0);
-        if (p->softcap > 0.f && variant == 0 && p->d <= 128 && !generic_only(p) && !p->alibi_slopes &&
+        if (((p->softcap > 0.f) != (p->alibi_slopes != nullptr)) && variant == 0 && p->d <= 128 && !generic_only(p) &&
             !p->block_table && p->p_dropout == 0.f && !nothing_ && split_plan(p, variant).splits <= 1 &&
             !(p->dtype == FA_DTYPE_FP8_E4M3 && fp8_native(p))) {
             variant = 4;

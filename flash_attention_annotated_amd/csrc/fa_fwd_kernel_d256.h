@@ -17,8 +17,8 @@
 //   * the steady state (runs of half-steps that need no mask) is the generated asm block fa::FastLoop256<T>
 //     (fa_fwd_loop_d256_gen.h, tools/gen_fwd_loop_d256.py); masks, tails and guard trips go through generic_half below, which
 //     shares the LDS images and the pipeline state with it.
-// Features: dense / varlen / seqused / leftpad, causal and sliding windows, GQA, softcap (SOFTCAP instantiations), a V head dim
-// of its own.  ALiBi, dropout, paged caches and split-KV keep the fwd_kernel<T, 256, 4> instantiations (fa_fwd_api.hip).
+// Features: dense / varlen / seqused / leftpad, causal and sliding windows, GQA, softcap (SOFTCAP instantiations), ALiBi (ALIBI
+// instantiations), a V head dim of its own.  Dropout, ALiBi together with softcap, paged caches and split-KV keep the fwd_kernel<T, 256, 4> instantiations (fa_fwd_api.hip).
 #pragma once
 
 #include "fa_fwd_kernel_w64.h"
@@ -56,8 +56,11 @@ __device__ __forceinline__ void dma_tile_d256(uint32_t lds, u32x4 desc, uint32_t
 // SOFTCAP: scores = softcap * tanh(q.k * softmax_scale / softcap) (set_params_fprop csrc/flash_attn/flash_api.cpp:103-117; Gemma-2's
 // head dim 256 + softcap): the generated block caps the fresh scores in place (FastLoop256<T, DEFF, true>), the generic
 // half-step right behind its score product.
-template <typename T, int DEFF, bool SOFTCAP = false>
+// ALIBI: bias -slope |row + sk - sq - key| on the score (csrc/flash_attn/src/alibi.h:18-71), in the block by three VALU per score
+// (FastLoop256<T, DEFF, false, true>), in the generic half-step between the cap and the mask (src/mask.h order).  Not with SOFTCAP.
+template <typename T, int DEFF, bool SOFTCAP = false, bool ALIBI = false>
 __global__ __launch_bounds__(256, 1) void fwd_kernel_d256(const KParams p) {
+    static_assert(!(SOFTCAP && ALIBI), "one of the two");
     constexpr int D = 256;
     constexpr int KS_EFF = DEFF / 16, DB_EFF = DEFF / 32;
     constexpr int BLOCK_M = 128;
@@ -254,6 +257,15 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_d256(const KParams p) {
             for (int i = 0; i < 16; ++i) s[i] = fast_tanh(s[i] * sc.softcap_pre);
         }
     };
+    const float alibi_raw = ALIBI ? load_alibi(p, sc, batch, head) : 0.f;   // slope in units of the raw score
+    auto alibi_scores = [&](int j, f32x16 &s) {
+        if constexpr (ALIBI) {
+            const int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            const int rel0 = wrow + (ln & 31) + shift - (n_min * BLOCK_N + 32 * j + 4 * (ln >> 5));
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s[i] -= alibi_raw * fabsf((float)(rel0 - ((i & 3) + 8 * (i >> 2))));
+        }
+    };
     auto mask_scores = [&](int j, f32x16 &s) {
         if (!half_needs_mask(j)) return;
         const int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -340,6 +352,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_d256(const KParams p) {
     if (jend > 0) {
         qk_half(0, 1, s);  // half-step 0 = second half of the shifted K tile n_min
         cap_scores(s);
+        alibi_scores(0, s);
         mask_scores(0, s);
         softmax(s, pc, alpha, moved);
         moved = false;     // O is still zero
@@ -365,6 +378,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_d256(const KParams p) {
             if (j + 1 < jend) {
                 qk_half(slot ^ 1, kb, s);
                 cap_scores(s);
+                alibi_scores(j + 1, s);
                 mask_scores(j + 1, s);
             }
             pv_half(slot, kb, pc);
@@ -412,6 +426,13 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_d256(const KParams p) {
                     FastLoop256<T, DEFF, true>::run(oa, qf, s, pc, pn, l_run, l_saved, m_run * csc, (uint32_t)kbase, (uint32_t)vbase, koff, voff,
                                         csc, LIM, kdesc, vdesc, ktile, vtile, (uint32_t)(BLOCK_N * k_rs * 2),
                                         (uint32_t)(BLOCK_N * v_rs * 2), lds0, lds_wave, (j >> 1) & 1, count, done, redo_mask, cap2);
+                } else if constexpr (ALIBI) {
+                    const int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+                    const int rrel = wrow + (ln & 31) + shift - (n_min * BLOCK_N + 32 * (j + 1) + 4 * (ln >> 5));
+                    float aslope = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, alibi_raw)));
+                    FastLoop256<T, DEFF, false, true>::run(oa, qf, s, pc, pn, l_run, l_saved, m_run * csc, (uint32_t)kbase, (uint32_t)vbase, koff, voff,
+                                        csc, LIM, kdesc, vdesc, ktile, vtile, (uint32_t)(BLOCK_N * k_rs * 2),
+                                        (uint32_t)(BLOCK_N * v_rs * 2), lds0, lds_wave, (j >> 1) & 1, count, done, redo_mask, aslope, rrel);
                 } else {
                 FastLoop256<T, DEFF>::run(oa, qf, s, pc, pn, l_run, l_saved, m_run * csc, (uint32_t)kbase, (uint32_t)vbase, koff, voff,
                                     csc, LIM, kdesc, vdesc, ktile, vtile, (uint32_t)(BLOCK_N * k_rs * 2),

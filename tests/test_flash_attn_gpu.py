@@ -90,11 +90,14 @@ def test_golden_cases(name, golden):
 
 
 @pytest.mark.parametrize("causal", [False, True])
-@pytest.mark.parametrize("sq,sk,d", [(113, 203, 64), (512, 512, 128), (1024, 1023, 64), (203, 113, 256), (2048, 2048, 128)])
+@pytest.mark.parametrize("sq,sk,d", [(113, 203, 64), (512, 512, 128), (1024, 1023, 64), (203, 113, 256), (2048, 2048, 128),
+                                     (1500, 1500, 40), (1300, 1700, 96), (1024, 2048, 160), (1111, 1111, 192), (1536, 1536, 256)])
 @pytest.mark.parametrize("per_batch", [False, True])
 def test_alibi(sq, sk, d, causal, per_batch):
     """ALiBi slopes (h) or (b, h), rand * 0.3 as tests/test_flash_attn.py:936-940; oracle bias from
-    attn_bias_from_alibi_slopes (:29-56, restated in oracle/ and pinned to the reference by make_golden.py)."""
+    attn_bias_from_alibi_slopes (:29-56, restated in oracle/ and pinned to the reference by make_golden.py).  The long sweeps
+    run the ALIBI form of the generated loop (FastLoop256<T, DEFF, false, true>: the 32-row-per-wave kernel shape at every head
+    dim, fa_fwd_api.hip variant 4 below 129), entered and left at the causal diagonal and the sequence tail."""
     fa = _api()
     torch.manual_seed(11)
     b, h, hk = 2, 4, 2

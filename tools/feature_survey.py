@@ -29,7 +29,7 @@ def visible(sq, sk, causal, window):
 
 dims = tuple(int(x) for x in sys.argv[1].split(",")) if len(sys.argv) > 1 else (64, 128, 256)
 feats = [("plain", {}), ("causal", dict(causal=True)), ("gqa4 causal", dict(causal=True, gqa=4)), ("softcap", dict(softcap=30.0)),
-         ("alibi causal", dict(causal=True, alibi=True)), ("window(1024,0)", dict(window_size=(1024, 0))),
+         ("alibi causal", dict(causal=True, alibi=True)), ("alibi geometric causal", dict(causal=True, alibi="geom")), ("window(1024,0)", dict(window_size=(1024, 0))),
          ("window(512,512)", dict(window_size=(512, 512))), ("varlen causal", dict(causal=True, varlen=True)),
          ("sk=4000 (ragged)", dict(sk=4000)), ("sq=1024 sk=4096 causal", dict(causal=True, sq=1024))]
 for d in dims:
@@ -40,7 +40,10 @@ for d in dims:
         sq, sk = kw.pop("sq", s), kw.pop("sk", s)
         hk = h // kw.pop("gqa", 1)
         varlen = kw.pop("varlen", False)
-        if kw.pop("alibi", False):
+        al = kw.pop("alibi", False)
+        if al == "geom":   # the slopes ALiBi models use: 2^(-8 (i + 1) / h)
+            kw["alibi_slopes"] = torch.tensor([2.0 ** (-8.0 * (i + 1) / h) for i in range(h)], device="cuda", dtype=torch.float32)
+        elif al:           # the reference's tests: rand * 0.3 (tests/test_flash_attn.py:937)
             kw["alibi_slopes"] = torch.rand(h, device="cuda") * 0.3
         q = torch.randn(b, sq, h, d, dtype=torch.bfloat16, device="cuda", requires_grad=True)
         k = torch.randn(b, sk, hk, d, dtype=torch.bfloat16, device="cuda", requires_grad=True)
@@ -59,4 +62,4 @@ for d in dims:
         tb = timeit(lambda: torch.autograd.grad(out, leaves, g, retain_graph=True), n=4)
         pairs = visible(sq, sk, kw.get("causal", False), kw.get("window_size", (-1, -1)))
         fl = 4.0 * b * h * d * pairs
-        print(f"d{d:3d} {name:24s} fwd {tf:7.3f} ms {fl / tf / 1e9:6.0f} TF   bwd {tb:7.3f} ms {2.5 * fl / tb / 1e9:6.0f} TF", flush=True)
+        print(f"d{d:3d} {name:26s} fwd {tf:7.3f} ms {fl / tf / 1e9:6.0f} TF   bwd {tb:7.3f} ms {2.5 * fl / tb / 1e9:6.0f} TF", flush=True)

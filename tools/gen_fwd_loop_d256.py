@@ -33,6 +33,7 @@ NPAIRS = 8                  # score pairs per 32 x 32 block and lane
 LD = 8                      # LDS-DMA pieces per wave, tile and matrix
 FD = 4                      # LDS fragments are fetched FD MFMAs ahead (every MFMA has a fragment of its own here)
 RING = FD + 1
+ALIBI = False               # variant that adds the ALiBi bias -slope |row + sk - sq - key| to the fresh scores in place (RREL, aslope)
 SOFTCAP = False             # variant that soft-caps the fresh scores in place (s <- tanh(s * pre)) in front of their softmax
 ABLATE = 0                  # developer-only timing ablations: 1 no LDS-DMA, 2 no guard, 8 no softmax VALU, 16 no barrier
 
@@ -43,6 +44,7 @@ KF, VF = 32, 52             # fragment rings, RING x 4 each
 KA, VA = 72, 88             # 16 + 16 LDS address registers
 KOFF, VOFF = 104, 112       # 8 + 8 LDS-DMA lane offsets
 MC, LA, LAS, T0, T1, PS0, PS1, TMP, KBASE, VBASE = 120, 121, 122, 123, 124, 125, 126, 127, 128, 129
+RREL = 130                  # ALIBI: (row + sk - sq) - (key base of the next scores + 4 (lane >> 5)) of this lane, -32 per half-step
 LAST = 129
 
 
@@ -88,6 +90,10 @@ def cvt_bf16(dst, t0, t1):
 def cvt_f16(dst, t0, t1):
     return [f"v_cvt_f16_f32 {v(dst)}, {v(t0)}",
             f"v_cvt_f16_f32_sdwa {v(dst)}, {v(t1)} dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD"]
+
+
+def keyoff(i):
+    return (i & 3) + 8 * (i >> 2)   # key of accumulator register i inside its 32-key block (+ 4 per lane half)
 
 
 def pairs_of(sl, nslices):
@@ -189,7 +195,15 @@ def gen_half(E, slot, KB, uid):
                         f"v_rcp_f32 {v(T0)}, {v(T0)}", f"v_rcp_f32 {v(T1)}, {v(T1)}"]
             def tanh_b(r0, r1):
                 return [f"v_fma_f32 {v(r0)}, {v(T0)}, -2.0, 1.0", f"v_fma_f32 {v(r1)}, {v(T1)}, -2.0, 1.0"]
+            def alibi_ops(r0, r1):  # s -= slope |rel|, rel = RREL - keyoff(register): sub, cvt, fma with |.| per score
+                i0 = r0 - S
+                return [f"v_subrev_u32 {v(T0)}, {keyoff(i0)}, {v(RREL)}", f"v_subrev_u32 {v(T1)}, {keyoff(i0 + 1)}, {v(RREL)}",
+                        f"v_cvt_f32_i32 {v(T0)}, {v(T0)}", f"v_cvt_f32_i32 {v(T1)}, {v(T1)}",
+                        f"v_fma_f32 {v(r0)}, |{v(T0)}|, -%[aslope], {v(r0)}", f"v_fma_f32 {v(r1)}, |{v(T1)}|, -%[aslope], {v(r1)}"]
             if st == 0:
+                if ALIBI:
+                    for ins in alibi_ops(s0, s1):
+                        E.e(ins)
                 if SOFTCAP:
                     for ins in tanh_a(s0, s1):
                         E.e(ins)
@@ -213,6 +227,9 @@ def gen_half(E, slot, KB, uid):
                 for ins in E.cvt(p_nxt + pr, t0, t1):
                     E.e(ins)
                 for pr2 in prs[1:]:     # (DEFF 192 / 160: 8 pairs over 6 / 5 slices)
+                    if ALIBI:
+                        for ins in alibi_ops(S + 2 * pr2, S + 2 * pr2 + 1):
+                            E.e(ins)
                     if SOFTCAP:
                         for ins in tanh_a(S + 2 * pr2, S + 2 * pr2 + 1) + tanh_b(S + 2 * pr2, S + 2 * pr2 + 1):
                             E.e(ins)
@@ -226,6 +243,8 @@ def gen_half(E, slot, KB, uid):
                         E.e(ins)
     if KB == 0:
         E.e("s_add_u32 %[vtile], %[vtile], %[vstep]")
+    if ALIBI:  # the next half-step's scores start 32 keys further on
+        E.e(f"v_subrev_u32 {v(RREL)}, 32, {v(RREL)}")
     E.e("s_add_u32 %[done], %[done], 1")
     if ABLATE & 2:
         return
@@ -297,10 +316,12 @@ namespace fa {
 // DEFF: head dims contracted / produced (256, or 192 / 160: the k-steps and O blocks of the zero padding are skipped)
 // SOFTCAP: the fresh scores are soft-capped in place before their softmax (cap2 = 2 log2(e) softmax_scale / softcap); on a guard
 // trip the scores the caller redoes P from are already capped.
-template <typename T, int DEFF, bool SOFTCAP = false> struct FastLoop256;
+// ALIBI: the fresh scores get the ALiBi bias in place (aslope = slope / softmax_scale, rrel = this lane's row + sk - sq minus the key
+// base of the first half-step's NEXT scores in its lane half; stepped by the block).
+template <typename T, int DEFF, bool SOFTCAP = false, bool ALIBI = false> struct FastLoop256;
 '''
 
-FUNC = '''template <> struct FastLoop256<%(T)s, %(DEFF)d, %(SC)s> {
+FUNC = '''template <> struct FastLoop256<%(T)s, %(DEFF)d, %(SC)s, %(AL)s> {
     static __device__ __forceinline__ void run(f32x16 (&oa)[8], u32x4 (&q)[16], f32x16 &s, u32x4 (&peven)[2], u32x4 (&podd)[2],
                                                float &l, float &l_saved, float mc, uint32_t kbase, uint32_t vbase,
                                                const uint32_t (&koff)[8], const uint32_t (&voff)[8], float csc, float lim,
@@ -313,7 +334,7 @@ FUNC = '''template <> struct FastLoop256<%(T)s, %(DEFF)d, %(SC)s> {
 %(body)s
             : %(accs)s,
               "+{v[0:15]}"(s), "+{v[16:19]}"(peven[0]), "+{v[20:23]}"(peven[1]), "+{v[24:27]}"(podd[0]), "+{v[28:31]}"(podd[1]),
-              "+{v%(LA)d}"(l), "+{v%(LAS)d}"(l_saved),
+              "+{v%(LA)d}"(l), "+{v%(LAS)d}"(l_saved)%(alout)s,
               [ktile] "+s"(ktile), [vtile] "+s"(vtile), [count] "+s"(count), [done] "+s"(done), [redo] "=&s"(redo),
               [m0save] "=&s"(m0save)
             : "{v%(MC)d}"(mc), "{v%(KBASE)d}"(kbase), "{v%(VBASE)d}"(vbase),
@@ -345,17 +366,20 @@ def main():
     offs = join([f'"{{v{KOFF + i}}}"(koff[{i}])' for i in range(8)] + [f'"{{v{VOFF + i}}}"(voff[{i}])' for i in range(8)])
     bound = set(range(0, 32)) | set(range(KOFF, KOFF + 16)) | {MC, LA, LAS, KBASE, VBASE}
     clob = "".join(f', "v{i}"' for i in range(LAST + 1) if i not in bound)
-    global DEFF, KSTEPS, NSTEP, SOFTCAP
-    for softcap in (False, True):
-        SOFTCAP = softcap
-        # (DEFF <= 128 exists for softcap only: head dims <= 128 with softcap run this kernel shape, fa_fwd_api.hip variant 4)
-        for deff in ((256, 192, 160, 128, 96, 64) if softcap else (256, 192, 160)):
+    global DEFF, KSTEPS, NSTEP, SOFTCAP, ALIBI
+    for softcap, alibi in ((False, False), (True, False), (False, True)):
+        SOFTCAP, ALIBI = softcap, alibi
+        # (DEFF <= 128 exists for softcap / ALiBi only: head dims <= 128 with one of them run this kernel shape, fa_fwd_api.hip variant 4)
+        for deff in ((256, 192, 160, 128, 96, 64) if (softcap or alibi) else (256, 192, 160)):
             DEFF, KSTEPS, NSTEP = deff, deff // 16, 2 * (deff // 32)
             for T, mf, cvt in (("__bf16", "v_mfma_f32_32x32x16_bf16", cvt_bf16), ("_Float16", "v_mfma_f32_32x32x16_f16", cvt_f16)):
+                capin = (', [cap2] "s"(cap2)' if softcap else "") + (', [aslope] "s"(aslope)' if alibi else "")
+                caparg = (", float cap2" if softcap else "") + (", float aslope, int rrel" if alibi else "")
                 text += "\n" + FUNC % {"T": T, "DEFF": deff, "body": render(gen_block(mf, cvt)), "accs": accs, "offs": offs,
                                        "clobbers": clob, "vregion": 2 * TILE, "LA": LA, "LAS": LAS, "MC": MC, "KBASE": KBASE,
-                                       "VBASE": VBASE, "SC": "true" if softcap else "false",
-                                       "caparg": ", float cap2" if softcap else "", "capin": ', [cap2] "s"(cap2)' if softcap else ""}
+                                       "VBASE": VBASE, "SC": "true" if softcap else "false", "AL": "true" if alibi else "false",
+                                       "caparg": caparg, "capin": capin,
+                                       "alout": f', "+{{v{RREL}}}"(rrel)' if alibi else ""}
     text += "\n}  // namespace fa\n"
     if "--check" in sys.argv:
         sys.exit(0 if os.path.exists(path) and open(path).read() == text else 1)
