@@ -309,10 +309,10 @@ def test_softcap(causal):
     assert err <= bound, (err, bound)
 
 
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("d", [40, 64, 72, 96, 128, 160, 192, 256])
+@pytest.mark.parametrize("d,dtype", [(40, torch.bfloat16), (64, torch.bfloat16), (72, torch.float16), (96, torch.bfloat16), (128, torch.bfloat16),
+                                     (128, torch.float16), (160, torch.bfloat16), (192, torch.float16), (256, torch.bfloat16), (256, torch.float16)])
 @pytest.mark.parametrize("sq,sk,causal,window", [(1024, 1024, False, (-1, -1)), (777, 1301, True, (-1, -1)),
-                                                 (1024, 1536, False, (300, 0)), (400, 400, False, (-1, -1)), (3000, 3000, True, (-1, -1))])
+                                                 (1024, 1536, False, (300, 0)), (400, 400, False, (-1, -1))])
 def test_softcap_head_dim_tile_256(sq, sk, causal, window, d, dtype):
     """Softcap on the head-dim-256 tile: the generated block FastLoop256<T, DEFF, true> caps the fresh scores in place (two
     interleaved tanh chains per score pair) and hands already-capped scores to the generic half-step on a guard trip; scores
