@@ -61,10 +61,12 @@ def scan(path, required=REQUIRED):
             if op.startswith('v_mfma') or op.startswith('v_cmp'):
                 for t in parts[:1]:
                     pass
-            if srcs_t & last_trans[0]:
+            # (both instructions compiler-scheduled with an s_waitcnt between them: LLVM's hazard recognizer counts that
+            #  instruction as the wait state -- its own code is its own responsibility; anything touching inline asm is ours)
+            if srcs_t & last_trans[0] and (in_asm or last_trans[3] or lineno == last_trans[2] + 1):
                 violations.append((kernel, last_trans[2], last_trans[1], lineno, l, 0))
         if op.startswith(TRANS):
-            last_trans = (regs(l.split(None, 1)[1].split(',')[0]), l, lineno)
+            last_trans = (regs(l.split(None, 1)[1].split(',')[0]), l, lineno, in_asm)
         elif op not in ('s_waitcnt',):
             last_trans = None
         # MFMA result read (or overwritten) by anything but a chained MFMA before the matrix pipe has written it
