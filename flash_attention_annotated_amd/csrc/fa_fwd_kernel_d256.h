@@ -257,6 +257,13 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_d256(const KParams p) {
             for (int i = 0; i < 16; ++i) s[i] = fast_tanh(s[i] * sc.softcap_pre);
         }
     };
+    // masked body of the block: this lane's last visible key minus the key base of half-step jn's scores in its lane half
+    auto mask_limit = [&](int jn) {
+        const int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        const int rr = wrow + (ln & 31) + shift;
+        const int last = p.window_right >= 0 ? min(sk - 1, rr + p.window_right) : sk - 1;
+        return last - (n_min * BLOCK_N + 32 * jn + 4 * (ln >> 5));
+    };
     const float alibi_raw = ALIBI ? load_alibi(p, sc, batch, head) : 0.f;   // slope in units of the raw score
     auto alibi_scores = [&](int j, f32x16 &s) {
         if constexpr (ALIBI) {
@@ -415,28 +422,37 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_d256(const KParams p) {
         // all need no mask and are all needed by this wave
         if ((j & 1) == 0 && !moved && !redo && addr32 && j + 1 >= fast_first) {
             int count = (min(fast_last, jend - 1) - j) >> 1;
+            // masked body of the block (round 3; not under ALiBi): what is left of this wave's range behind its last mask-free tile
+            // -- the diagonal tiles under a causal / right-window mask, the tail tile of a sequence that is not a multiple of 64, the
+            // last tile of any sweep (its look-ahead scores lie behind the end) -- as whole tiles: a trailing half-step the wave
+            // does not need is fully masked (P = 0, row sums 0)
+            const bool masked_run = !ALIBI && count < 1 && j < jend;
+            if (masked_run) count = (jend - j + 1) >> 1;
             if (count >= 1 && !__any(m_run == -INFINITY)) {
                 const int n_cur = n_min + (j >> 1);
                 uint32_t ktile = (uint32_t)(((n_cur + 2) * BLOCK_N - 32) * k_rs * 2);
                 uint32_t vtile = (uint32_t)((n_cur + 1) * BLOCK_N * v_rs * 2);
                 int done = 0;
                 uint64_t redo_mask = 0;
+                const uint32_t kstep_ = (uint32_t)(BLOCK_N * k_rs * 2), vstep_ = (uint32_t)(BLOCK_N * v_rs * 2);
+                const int slot0_ = (j >> 1) & 1;
+                const float mc_ = m_run * csc;
+                const int masked_ = __builtin_amdgcn_readfirstlane(masked_run ? 1 : 0);   // (an SGPR operand of the block)
                 if constexpr (SOFTCAP) {
                     float cap2 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sc.softcap_pre * 2.885390081777927f)));
-                    FastLoop256<T, DEFF, true>::run(oa, qf, s, pc, pn, l_run, l_saved, m_run * csc, (uint32_t)kbase, (uint32_t)vbase, koff, voff,
-                                        csc, LIM, kdesc, vdesc, ktile, vtile, (uint32_t)(BLOCK_N * k_rs * 2),
-                                        (uint32_t)(BLOCK_N * v_rs * 2), lds0, lds_wave, (j >> 1) & 1, count, done, redo_mask, cap2);
+                    FastLoop256<T, DEFF, true>::run(oa, qf, s, pc, pn, l_run, l_saved, mc_, (uint32_t)kbase, (uint32_t)vbase, koff, voff,
+                                        csc, LIM, kdesc, vdesc, ktile, vtile, kstep_, vstep_, lds0, lds_wave, slot0_, count, done, redo_mask, cap2,
+                                        masked_, mask_limit(j + 1));
                 } else if constexpr (ALIBI) {
                     const int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
                     const int rrel = wrow + (ln & 31) + shift - (n_min * BLOCK_N + 32 * (j + 1) + 4 * (ln >> 5));
                     float aslope = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, alibi_raw)));
-                    FastLoop256<T, DEFF, false, true>::run(oa, qf, s, pc, pn, l_run, l_saved, m_run * csc, (uint32_t)kbase, (uint32_t)vbase, koff, voff,
-                                        csc, LIM, kdesc, vdesc, ktile, vtile, (uint32_t)(BLOCK_N * k_rs * 2),
-                                        (uint32_t)(BLOCK_N * v_rs * 2), lds0, lds_wave, (j >> 1) & 1, count, done, redo_mask, aslope, rrel);
+                    FastLoop256<T, DEFF, false, true>::run(oa, qf, s, pc, pn, l_run, l_saved, mc_, (uint32_t)kbase, (uint32_t)vbase, koff, voff,
+                                        csc, LIM, kdesc, vdesc, ktile, vtile, kstep_, vstep_, lds0, lds_wave, slot0_, count, done, redo_mask, aslope, rrel);
                 } else {
-                FastLoop256<T, DEFF>::run(oa, qf, s, pc, pn, l_run, l_saved, m_run * csc, (uint32_t)kbase, (uint32_t)vbase, koff, voff,
-                                    csc, LIM, kdesc, vdesc, ktile, vtile, (uint32_t)(BLOCK_N * k_rs * 2),
-                                    (uint32_t)(BLOCK_N * v_rs * 2), lds0, lds_wave, (j >> 1) & 1, count, done, redo_mask);
+                    FastLoop256<T, DEFF>::run(oa, qf, s, pc, pn, l_run, l_saved, mc_, (uint32_t)kbase, (uint32_t)vbase, koff, voff,
+                                        csc, LIM, kdesc, vdesc, ktile, vtile, kstep_, vstep_, lds0, lds_wave, slot0_, count, done, redo_mask,
+                                        masked_, mask_limit(j + 1));
                 }
                 j += done;
                 redo = redo_mask != 0;

@@ -33,6 +33,8 @@ NPAIRS = 8                  # score pairs per 32 x 32 block and lane
 LD = 8                      # LDS-DMA pieces per wave, tile and matrix
 FD = 4                      # LDS fragments are fetched FD MFMAs ahead (every MFMA has a fragment of its own here)
 RING = FD + 1
+MASKED = False              # loop body that masks the fresh scores (key > RA -> -inf: causal / right window / sequence end) before their softmax
+LBL = "fd"                  # label prefix of the loop body being emitted (the unmasked and the masked body share one asm statement)
 ALIBI = False               # variant that adds the ALiBi bias -slope |row + sk - sq - key| to the fresh scores in place (RREL, aslope)
 SOFTCAP = False             # variant that soft-caps the fresh scores in place (s <- tanh(s * pre)) in front of their softmax
 ABLATE = 0                  # developer-only timing ablations: 1 no LDS-DMA, 2 no guard, 8 no softmax VALU, 16 no barrier
@@ -44,6 +46,7 @@ KF, VF = 32, 52             # fragment rings, RING x 4 each
 KA, VA = 72, 88             # 16 + 16 LDS address registers
 KOFF, VOFF = 104, 112       # 8 + 8 LDS-DMA lane offsets
 MC, LA, LAS, T0, T1, PS0, PS1, TMP, KBASE, VBASE = 120, 121, 122, 123, 124, 125, 126, 127, 128, 129
+RA, NINF = 131, 132         # masked body: this lane's last visible key minus the key base of the next scores (+ 4 per lane half), -32 per half-step; -inf
 RREL = 130                  # ALIBI: (row + sk - sq) - (key base of the next scores + 4 (lane >> 5)) of this lane, -32 per half-step
 LAST = 129
 
@@ -200,6 +203,13 @@ def gen_half(E, slot, KB, uid):
                 return [f"v_subrev_u32 {v(T0)}, {keyoff(i0)}, {v(RREL)}", f"v_subrev_u32 {v(T1)}, {keyoff(i0 + 1)}, {v(RREL)}",
                         f"v_cvt_f32_i32 {v(T0)}, {v(T0)}", f"v_cvt_f32_i32 {v(T1)}, {v(T1)}",
                         f"v_fma_f32 {v(r0)}, |{v(T0)}|, -%[aslope], {v(r0)}", f"v_fma_f32 {v(r1)}, |{v(T1)}|, -%[aslope], {v(r1)}"]
+            def mask_ops(r0, r1):   # behind cap and bias, in front of the exponentials: register i is key base + keyoff(i)
+                if not MASKED:
+                    return []
+                out = []
+                for r_ in (r0, r1):
+                    out += [f"v_cmp_gt_i32 vcc, {keyoff(r_ - S)}, {v(RA)}", f"v_cndmask_b32 {v(r_)}, {v(r_)}, {v(NINF)}, vcc"]
+                return out
             if st == 0:
                 if ALIBI:
                     for ins in alibi_ops(s0, s1):
@@ -208,12 +218,14 @@ def gen_half(E, slot, KB, uid):
                     for ins in tanh_a(s0, s1):
                         E.e(ins)
                 else:
+                    for ins in mask_ops(s0, s1):
+                        E.e(ins)
                     E.e(f"v_fma_f32 {v(t0)}, {v(s0)}, %[csc], -{v(MC)}")
                     E.e(f"v_fma_f32 {v(t1)}, {v(s1)}, %[csc], -{v(MC)}")
                     E.e(f"v_exp_f32 {v(t0)}, {v(t0)}")
             else:
                 if SOFTCAP:
-                    for ins in tanh_b(s0, s1):
+                    for ins in tanh_b(s0, s1) + mask_ops(s0, s1):
                         E.e(ins)
                     E.e(f"v_fma_f32 {v(t0)}, {v(s0)}, %[csc], -{v(MC)}")
                     E.e(f"v_fma_f32 {v(t1)}, {v(s1)}, %[csc], -{v(MC)}")
@@ -233,6 +245,8 @@ def gen_half(E, slot, KB, uid):
                     if SOFTCAP:
                         for ins in tanh_a(S + 2 * pr2, S + 2 * pr2 + 1) + tanh_b(S + 2 * pr2, S + 2 * pr2 + 1):
                             E.e(ins)
+                    for ins in mask_ops(S + 2 * pr2, S + 2 * pr2 + 1):
+                        E.e(ins)
                     E.e(f"v_fma_f32 {v(T0)}, {v(S + 2 * pr2)}, %[csc], -{v(MC)}")
                     E.e(f"v_fma_f32 {v(T1)}, {v(S + 2 * pr2 + 1)}, %[csc], -{v(MC)}")
                     E.e(f"v_exp_f32 {v(T0)}, {v(T0)}")
@@ -245,6 +259,8 @@ def gen_half(E, slot, KB, uid):
         E.e("s_add_u32 %[vtile], %[vtile], %[vstep]")
     if ALIBI:  # the next half-step's scores start 32 keys further on
         E.e(f"v_subrev_u32 {v(RREL)}, 32, {v(RREL)}")
+    if MASKED:
+        E.e(f"v_subrev_u32 {v(RA)}, 32, {v(RA)}")
     E.e("s_add_u32 %[done], %[done], 1")
     if ABLATE & 2:
         return
@@ -271,26 +287,40 @@ def gen_block(mfma, cvt):
     for i in range(16):
         E.e(f"v_add_u32 {v(KA + i)}, %[lds0], {v(KA + i)}")
         E.e(f"v_add_u32 {v(VA + i)}, %[lds0v], {v(VA + i)}")
-    # entry: the first FD K fragments of the first half-step (KB = 0 of ring slot slot0: K tile t+1 sits in slot slot0 ^ 1)
-    E.e("s_cmp_eq_u32 %[slot0], 1")
-    E.e(f"s_cbranch_scc1 .Lfd_in1_{u}")
-    for s in range(2):
-        if s:
-            E.label(f".Lfd_in{s}_{u}")
-        E.lds_q = []
-        for i in range(FD):
-            E.ds_k(KF + 4 * i, i, (s ^ 1) * TILE, ("k", 1000 + 2 * s, i))
-        E.e(f"s_branch .Lfd_t{s}_{u}")
-    for s in range(2):
-        E.label(f".Lfd_t{s}_{u}")
-        E.lds_q = [("k", 1000 + 2 * s, i) for i in range(FD)]
-        gen_half(E, s, 0, 1000 + 2 * s)
-        gen_half(E, s, 1, 1000 + 2 * s + 1)
-        E.e("s_sub_u32 %[count], %[count], 1")
-        E.e("s_cmp_eq_u32 %[count], 0")
-        E.e(f"s_cbranch_scc1 .Lfd_exit_{u}")
-        if s == 1:
-            E.e(f"s_branch .Lfd_t0_{u}")
+    # Two loop bodies in ONE asm statement (one register map for hipcc: a second statement around the same O / Q operands made it
+    # spill at the block boundaries, measured -6 .. -25 %): the unmasked body and -- entered when %[masked] != 0 -- the body that
+    # masks the fresh scores (the diagonal / tail tiles of a wave).  The ALiBi form has the unmasked body only.
+    global MASKED, LBL
+    bodies = [(False, "fd")] if ALIBI else [(False, "fd"), (True, "fdm")]
+    if len(bodies) > 1:
+        E.e(f"v_mov_b32 {v(NINF)}, 0xff800000")
+        E.e("s_cmp_lg_u32 %[masked], 0")
+        E.e(f"s_cbranch_scc1 .Lfdm_entry_{u}")
+    for masked, lbl in bodies:
+        MASKED, LBL = masked, lbl
+        if masked:
+            E.label(f".L{lbl}_entry_{u}")
+        # entry: the first FD K fragments of the first half-step (KB = 0 of ring slot slot0: K tile t+1 sits in slot slot0 ^ 1)
+        E.e("s_cmp_eq_u32 %[slot0], 1")
+        E.e(f"s_cbranch_scc1 .L{lbl}_in1_{u}")
+        for s_ in range(2):
+            if s_:
+                E.label(f".L{lbl}_in{s_}_{u}")
+            E.lds_q = []
+            for i in range(FD):
+                E.ds_k(KF + 4 * i, i, (s_ ^ 1) * TILE, ("k", 1000 + 2 * s_, i))
+            E.e(f"s_branch .L{lbl}_t{s_}_{u}")
+        for s_ in range(2):
+            E.label(f".L{lbl}_t{s_}_{u}")
+            E.lds_q = [("k", 1000 + 2 * s_, i) for i in range(FD)]
+            gen_half(E, s_, 0, 1000 + 2 * s_)
+            gen_half(E, s_, 1, 1000 + 2 * s_ + 1)
+            E.e("s_sub_u32 %[count], %[count], 1")
+            E.e("s_cmp_eq_u32 %[count], 0")
+            E.e(f"s_cbranch_scc1 .Lfd_exit_{u}")
+            if s_ == 1:
+                E.e(f"s_branch .L{lbl}_t0_{u}")
+    MASKED, LBL = False, "fd"
     E.label(f".Lfd_exit_{u}")
     E.e("s_waitcnt lgkmcnt(0)")
     E.e("s_nop 15")
@@ -318,6 +348,9 @@ namespace fa {
 // trip the scores the caller redoes P from are already capped.
 // ALIBI: the fresh scores get the ALiBi bias in place (aslope = slope / softmax_scale, rrel = this lane's row + sk - sq minus the key
 // base of the first half-step's NEXT scores in its lane half; stepped by the block).
+// masked != 0 (all but the ALiBi form): the body that gives the fresh scores the causal / right-window / end-of-sequence mask is run
+// (key > limit -> -inf; ra = the lane's last visible key minus the key base of the first half-step's NEXT scores in its lane half):
+// the diagonal and tail tiles of a wave.  Both bodies live in one asm statement.
 template <typename T, int DEFF, bool SOFTCAP = false, bool ALIBI = false> struct FastLoop256;
 '''
 
@@ -373,13 +406,13 @@ def main():
         for deff in ((256, 192, 160, 128, 96, 64) if (softcap or alibi) else (256, 192, 160)):
             DEFF, KSTEPS, NSTEP = deff, deff // 16, 2 * (deff // 32)
             for T, mf, cvt in (("__bf16", "v_mfma_f32_32x32x16_bf16", cvt_bf16), ("_Float16", "v_mfma_f32_32x32x16_f16", cvt_f16)):
-                capin = (', [cap2] "s"(cap2)' if softcap else "") + (', [aslope] "s"(aslope)' if alibi else "")
-                caparg = (", float cap2" if softcap else "") + (", float aslope, int rrel" if alibi else "")
+                capin = (', [cap2] "s"(cap2)' if softcap else "") + (', [aslope] "s"(aslope)' if alibi else ', [masked] "s"(masked)')
+                caparg = (", float cap2" if softcap else "") + (", float aslope, int rrel" if alibi else ", int masked, int ra")
                 text += "\n" + FUNC % {"T": T, "DEFF": deff, "body": render(gen_block(mf, cvt)), "accs": accs, "offs": offs,
-                                       "clobbers": clob, "vregion": 2 * TILE, "LA": LA, "LAS": LAS, "MC": MC, "KBASE": KBASE,
+                                       "clobbers": clob + ("" if alibi else f', "v{NINF}"'), "vregion": 2 * TILE, "LA": LA, "LAS": LAS, "MC": MC, "KBASE": KBASE,
                                        "VBASE": VBASE, "SC": "true" if softcap else "false", "AL": "true" if alibi else "false",
                                        "caparg": caparg, "capin": capin,
-                                       "alout": f', "+{{v{RREL}}}"(rrel)' if alibi else ""}
+                                       "alout": f', "+{{v{RREL}}}"(rrel)' if alibi else f', "+{{v{RA}}}"(ra)'}
     text += "\n}  // namespace fa\n"
     if "--check" in sys.argv:
         sys.exit(0 if os.path.exists(path) and open(path).read() == text else 1)
