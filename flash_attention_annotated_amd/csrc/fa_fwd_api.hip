@@ -547,7 +547,7 @@ bool persist_ok(const fa::KParams &kp) {
     if (mode < 0) return false;
     if (kp.cu_seqlens_q || kp.cu_seqlens_k || kp.seqused_q || kp.seqused_k || kp.leftpad_k || kp.kv_batch_idx || kp.block_table) return false;
     if (kp.alibi || kp.q_descale || kp.k_descale || kp.v_descale || kp.num_splits > 1 || kp.rp_dropout != 1.f) return false;
-    if (kp.d <= 96 || kp.d > 128 || kp.window_left >= 0) return false;
+    if (kp.d <= 96 || kp.d > 128) return false;   // (left windows: the next item's first tile is its own n_min, round 3)
     if (kp.seqlen_k % 64 != 0 || kp.seqlen_k < 192 || kp.seqlen_q > kp.seqlen_k) return false;  // (causal: bottom-right aligned, shift >= 0)
     if ((kp.num_cus & ~7) < 8) return false;
     // the kernel decodes its chain once into 32-bit entries (m_block 12 bits, head 10, batch 10), one lane per round
@@ -560,6 +560,10 @@ bool persist_ok(const fa::KParams &kp) {
         extent(kp.v_batch_stride, kp.v_head_stride, kp.v_row_stride, 0) >= (1ll << 32) - 65536) return false;
     if ((int64_t)kp.seqlen_k * kp.k_row_stride >= (1ll << 30) || (int64_t)kp.seqlen_k * kp.v_row_stride >= (1ll << 30)) return false;
     if (mode > 0) return true;
+    // left windows: supported (bit-identical to the hand-over kernel, tests/test_persistent_gpu.py) but measured SLOWER there --
+    // b4 s4096 window (1024, 0) 538 -> 472, (512, 512) 530 -> 469, s16384 (4096, 0) 825 -> 782 TFLOP/s: a windowed item spends its
+    // first tiles on the generic half-step (the left edge), where the cross-item look-ahead stream buys nothing -- not dispatched
+    if (kp.window_left >= 0) return false;
     // chains of one item gain nothing; from two items per CU on the persistent form wins or ties on the whole benchmark grid
     // (profiles/r3_persist_sweep.txt: non-causal s512 .. 16k +10 / +5 / +2 / 0 %, causal +21 / +26 / +15 / +11 / +3 / +1 %)
     return kp.grid > (kp.num_cus & ~7);

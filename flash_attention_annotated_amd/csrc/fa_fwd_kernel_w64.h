@@ -510,6 +510,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
     int chain_round = 0;
     bool has_next = false;
     int m_block_n = 0, head_n = 0, batch_n = 0;
+    int n_min_nx = 0;  // first key tile of the next item (> 0 under a left window; dense batches: the same shift for every item)
     const T *kp_n = kp, *vp_n = vp;
     // The chain is decoded once, lane t = round t (the host keeps chains at <= 64 rounds and every field inside its bits):
     // m_block << 20 | head << 10 | batch, or ~0 for a round without an item for this CU.  In the item loop a round is one
@@ -542,6 +543,10 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
             m_block_n = (int)(e >> 20);
             chain_round = t;
             has_next = true;
+            n_min_nx = 0;
+            if (p.window_left >= 0) {  // item_geometry()'s key_lo of the next item (no split-KV, no varlen here)
+                n_min_nx = max(0, m_block_n * 256 + (p.seqlen_k - p.seqlen_q) - p.window_left) / BLOCK_N;  // (dense: persist_ok)
+            }
             break;
         }
     };
@@ -670,17 +675,17 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
         }
     };
     // K tile m = keys [64m - 32, 64m + 32)
-    // PERSIST: tiles behind the item's last one are the NEXT item's first ones (n_min = 0 there).  K tile n_max is a hybrid:
+    // PERSIST: tiles behind the item's last one are the NEXT item's first ones (its tile n_min_nx + i; 0 without a left window).  K tile n_max is a hybrid:
     // rows 0..31 = this item's last 32 keys (waves 0 and 1 fetch them), rows 32..63 = the next item's keys 0..31 (waves 2, 3).
     auto load_k = [&](int m, int buf) {
         if (PERSIST && has_next && (m > n_max || (m == n_max && wave >= 2)))
-            dma_tile(kp_n, k_rs, k_rs64, koff, (m - n_max) * BLOCK_N - 32, lds_wave + buf * TILE_BYTES);
+            dma_tile(kp_n, k_rs, k_rs64, koff, (m - n_max + n_min_nx) * BLOCK_N - 32, lds_wave + buf * TILE_BYTES);
         else
             dma_tile(kp, k_rs, k_rs64, koff, m * BLOCK_N - 32, lds_wave + buf * TILE_BYTES);
     };
     auto load_v = [&](int n, int buf) {
         if (PERSIST && has_next && n >= n_max)
-            dma_tile(vp_n, v_rs, v_rs64, voff, (n - n_max) * BLOCK_N, lds_wave + (3 + buf) * TILE_BYTES);
+            dma_tile(vp_n, v_rs, v_rs64, voff, (n - n_max + n_min_nx) * BLOCK_N, lds_wave + (3 + buf) * TILE_BYTES);
         else
             dma_tile(vp, v_rs, v_rs64, voff, n * BLOCK_N, lds_wave + (3 + buf) * TILE_BYTES);
     };
@@ -1340,8 +1345,8 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel_w64(const KParams p) {
                         const int k_first = n_max + 1 - (wave >= 2 ? 1 : 0);  // first K tile index that is the next item's
                         kswc = (uint32_t)max(0, k_first - mk);
                         vswc = (uint32_t)max(0, n_max - mv);
-                        ktile_nx = (uint32_t)((const char *)kp_n - (const char *)p.k) + (uint32_t)(max(mk, k_first) - n_max) * kstep;
-                        vtile_nx = (uint32_t)((const char *)vp_n - (const char *)p.v) + (uint32_t)(max(mv, n_max) - n_max) * vstep;
+                        ktile_nx = (uint32_t)((const char *)kp_n - (const char *)p.k) + (uint32_t)(max(mk, k_first) - n_max + n_min_nx) * kstep;
+                        vtile_nx = (uint32_t)((const char *)vp_n - (const char *)p.v) + (uint32_t)(max(mv, n_max) - n_max + n_min_nx) * vstep;
                     }
                 } else {
                     kdesc = make_desc(kp, k_rs64);

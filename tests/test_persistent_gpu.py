@@ -49,6 +49,29 @@ def test_persistent_is_bit_identical_to_handover(shape, dtype):
     assert not torch.isnan(o1).any()
 
 
+@pytest.mark.parametrize("window", [(1024, 0), (512, 512), (300, -1), (64, 0), (4096, 0), (200, 77)])
+@pytest.mark.parametrize("shape", [(4, 4096, 4096, 16, 16, 128), (2, 2048, 4096, 24, 8, 128), (8, 1024, 1024, 16, 4, 104), (1, 8192, 8192, 20, 20, 128)])
+def test_persistent_under_sliding_windows(shape, window):
+    """Left windows in the persistent form (round 3): the next item's first key tile is its own n_min -- the look-ahead stream of
+    an item's last tiles, the hybrid K tile and the switch offsets of the generated block all start there.  Bit-identical to the
+    hand-over kernel; one shape also against the oracle."""
+    b, sq, sk, h, hk, d = shape
+    g = torch.Generator(device=DEV).manual_seed(sq + window[0])
+    q = torch.randn(b, sq, h, d, device=DEV, dtype=torch.bfloat16, generator=g)
+    k = torch.randn(b, sk, hk, d, device=DEV, dtype=torch.bfloat16, generator=g)
+    v = torch.randn(b, sk, hk, d, device=DEV, dtype=torch.bfloat16, generator=g)
+    o0, l0 = _run(-1, q, k, v, window_size=window)
+    o1, l1 = _run(1, q, k, v, window_size=window)
+    assert torch.equal(o0, o1) and torch.equal(l0, l1)
+    assert not torch.isnan(o1).any()
+    if sq == 1024:
+        ref_window = (window[0], sk) if (window[0] >= 0 and window[1] < 0) else window
+        out_ref, _ = oracle.attention_ref(q.cpu(), k.cpu(), v.cpu(), window_size=ref_window)
+        out_pt, _ = oracle.attention_ref(q.cpu(), k.cpu(), v.cpu(), window_size=ref_window, upcast=False, reorder_ops=True)
+        err = (o1.float().cpu() - out_ref.float()).abs().max().item()
+        assert err <= 2 * (out_pt.float() - out_ref.float()).abs().max().item() + 1e-5
+
+
 @pytest.mark.parametrize("causal", [False, True])
 def test_persistent_against_oracle(causal):
     """A chain-carrying problem small enough for the fp32 oracle: 1536 tiles on 256 CUs = 6 items per CU, GQA 3:1, strided
