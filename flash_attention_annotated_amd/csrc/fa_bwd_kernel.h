@@ -307,6 +307,10 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_kernel(const BParams p) {
 
     int n_block, kv_head, batch;
     if (!decode_block(p, n_block, kv_head, batch, p.h_k)) return;
+    // decode_block() deals the blocks of a unit from the last to the first -- the heaviest QUERY block of a causal problem
+    // first, right for the dQ sweep.  Key blocks are the other way round: block 0 is seen by every row, the last one by the
+    // fewest.  Heaviest first here too, so that the launch ends on light workgroups.
+    n_block = p.num_blocks - 1 - n_block;
     const BSeq sq_ = bwd_seq(p, batch);
     const int sq = sq_.sq, sk = sq_.sk;
     const int n0 = n_block * BLOCK_K;
