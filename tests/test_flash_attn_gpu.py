@@ -547,3 +547,44 @@ def test_empty_keys_dense():
     k = torch.empty(1, 0, 2, 64, dtype=torch.bfloat16, device=DEV)
     out, lse, _ = fa.flash_attn_func(q, k, k, return_attn_probs=True)
     assert torch.all(out == 0) and torch.all(torch.isposinf(lse))
+
+
+@pytest.mark.parametrize("seed", list(range(40)))
+def test_row_block_kernel_random_sweep(seed):
+    """Seeded random problems over everything the 32-row-per-wave kernel (fa_fwd_kernel_d256.h) takes since round 3: head dims
+    40 .. 256 with softcap or ALiBi (its DEFF 64 .. 256 forms), head dims 136 .. 256 plain, causal / windows / neither, GQA,
+    odd lengths, both 16-bit types -- unmasked body, masked body (diagonal, ragged tail, last tile) and the generic half-step
+    (left window edge, guard trips) in one sweep each; out and LSE against the oracle."""
+    fa = _api()
+    g = torch.Generator().manual_seed(1000 + seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g).item())
+    feature = ("softcap", "alibi", "plain")[seed % 3]
+    d = 8 * ri(17, 32) if feature == "plain" else 8 * ri(5, 32)
+    dtype = (torch.bfloat16, torch.float16)[ri(0, 1)]
+    sq, sk = ri(300, 1800), ri(600, 2200)
+    if ri(0, 2) == 0:
+        sq = sk
+    hk = ri(1, 2)
+    h = hk * ri(1, 3)
+    mask = ri(0, 3)
+    kw = dict(causal=True) if mask == 1 else (dict(window_size=(ri(50, 700), ri(0, 200))) if mask == 2 else
+                                              (dict(window_size=(ri(100, 500), -1)) if mask == 3 else {}))
+    q = torch.randn(2, sq, h, d, generator=g).to(dtype)
+    k = torch.randn(2, sk, hk, d, generator=g).to(dtype)
+    v = torch.randn(2, sk, hk, d, generator=g).to(dtype)
+    okw = dict(kw)
+    if "window_size" in kw and kw["window_size"][1] < 0:
+        okw["window_size"] = (kw["window_size"][0], sk)   # (the FA2 entry point's mirror rule, csrc/flash_attn/flash_api.cpp:141-142)
+    if feature == "softcap":
+        kw["softcap"] = okw["softcap"] = 12.0 + ri(0, 30)
+        q = q * (kw["softcap"] / 4)
+    elif feature == "alibi":
+        slopes = torch.rand(2, h, generator=g) * 0.05   # (small slopes: the block is not left at every tile)
+        kw["alibi_slopes"] = slopes.to(DEV)
+        okw["attn_bias"] = oracle.attn_bias_from_alibi_slopes(slopes, sq, sk, causal=False)
+    out, lse, _ = fa.flash_attn_func(q.to(DEV), k.to(DEV), v.to(DEV), return_attn_probs=True, **kw)
+    out_ref, out_pt, lse_ref = _dense_ref(q, k, v, **okw)
+    err = (out.float().cpu() - out_ref.float()).abs().max().item()
+    bound = 3 * (out_pt.float() - out_ref.float()).abs().max().item() + 2 * (out_ref + 0.3 - 0.3 - out_ref).abs().max().item() + 1e-5
+    assert err <= bound, (feature, d, sq, sk, kw.keys(), err, bound)
+    _check_lse(lse, lse_ref, tol=5e-3)
