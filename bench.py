@@ -319,7 +319,7 @@ def main():
     if world > 1 or os.environ.get("FA_BENCH_FORCE_DIST"):  # (the env switch rehearses this path on one GPU)
         import datetime
         import torch.distributed as dist
-        RENDEZVOUS_TIMEOUT = datetime.timedelta(seconds=int(os.environ.get("FA_BENCH_RENDEZVOUS_S", "180")))
+        RENDEZVOUS_TIMEOUT = datetime.timedelta(seconds=int(os.environ.get("FA_BENCH_RENDEZVOUS_S", "600")))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # single node; the container hostname may not resolve
         # RCCL prints a version banner on stdout when it initialises: keep stdout for the one JSON line
