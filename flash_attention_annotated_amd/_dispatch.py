@@ -172,7 +172,7 @@ def rotary_apply(src, dst, cos, sin, seqlen_offsets, interleaved, per_row_positi
 
 
 def kvcache_append(k_new, v_new, k_cache, v_cache, cache_seqlens, cache_batch_idx=None, block_table=None,
-                   rotary_cos=None, rotary_sin=None, rotary_interleaved=False):
+                   rotary_cos=None, rotary_sin=None, rotary_interleaved=False, rotary_seqlens=None):
     """(b, s_new, h_k, d) rows appended in place to (b_cache, s_cache, h_k, d) caches at cache_seqlens (int32, (b,))."""
     lib = _lib.load()
     prm = _lib.FaKvcacheAppendParams()
@@ -197,6 +197,7 @@ def kvcache_append(k_new, v_new, k_cache, v_cache, cache_seqlens, cache_batch_id
         prm.rotary_cos, prm.rotary_sin = ptr(rotary_cos), ptr(rotary_sin)
         prm.rotary_dim = rotary_cos.shape[1] * 2
         prm.rotary_interleaved = int(bool(rotary_interleaved))
+        prm.rotary_seqlens = ptr(rotary_seqlens)   # FA3 seqlens_rotary (None: the cache fill levels)
     stream = torch.cuda.current_stream(k_new.device).cuda_stream
     st = lib.fa_kvcache_append(ctypes.byref(prm), ctypes.c_void_p(stream))
     if st != 0:

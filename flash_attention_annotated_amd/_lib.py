@@ -144,7 +144,7 @@ class FaKvcacheAppendParams(ctypes.Structure):
         + [("block_table", ctypes.c_void_p), ("block_table_batch_stride", ctypes.c_int64),
            ("page_block_size", ctypes.c_int32), ("dtype", ctypes.c_int32)]
         + [("rotary_cos", ctypes.c_void_p), ("rotary_sin", ctypes.c_void_p),
-           ("rotary_dim", ctypes.c_int32), ("rotary_interleaved", ctypes.c_int32)]
+           ("rotary_dim", ctypes.c_int32), ("rotary_interleaved", ctypes.c_int32), ("rotary_seqlens", ctypes.c_void_p)]
     )
 
 

@@ -164,7 +164,7 @@ __global__ void kvcache_append_kernel(const fa_kvcache_append_params p) {
         const int b = (int)(t / p.seqlen_new);
         int dst_row = p.cache_seqlens[b] + row;
         if (dst_row < 0 || dst_row >= p.seqlen_cache) continue;
-        const int pos = dst_row;
+        const int pos = p.rotary_seqlens ? p.rotary_seqlens[b] + row : dst_row;   // (FA3 seqlens_rotary; default: the cache row)
         int cb = p.cache_batch_idx ? p.cache_batch_idx[b] : b;
         if (p.block_table) {
             cb = p.block_table[b * p.block_table_batch_stride + dst_row / p.page_block_size];

@@ -564,7 +564,8 @@ void rotary_apply(const Tensor &src, const Tensor &dst, const Tensor &cos, const
 
 void kvcache_append(const Tensor &k_new, const Tensor &v_new, const Tensor &k_cache, const Tensor &v_cache,
                     const Tensor &cache_seqlens, const OptTensor &cache_batch_idx, const OptTensor &block_table,
-                    const OptTensor &rotary_cos, const OptTensor &rotary_sin, bool rotary_interleaved) {
+                    const OptTensor &rotary_cos, const OptTensor &rotary_sin, bool rotary_interleaved,
+                    const OptTensor &rotary_seqlens = c10::nullopt) {
     fa_kvcache_append_params p{};
     p.abi_version = FA_ABI_VERSION;
     p.struct_size = sizeof(fa_kvcache_append_params);
@@ -588,6 +589,7 @@ void kvcache_append(const Tensor &k_new, const Tensor &v_new, const Tensor &k_ca
         p.rotary_cos = rotary_cos->data_ptr(); p.rotary_sin = rotary_sin->data_ptr();
         p.rotary_dim = (int32_t)rotary_cos->size(1) * 2;
         p.rotary_interleaved = rotary_interleaved ? 1 : 0;
+        p.rotary_seqlens = static_cast<const int32_t *>(ptr(rotary_seqlens));   // FA3 seqlens_rotary (NULL: the cache fill levels)
     }
     const int st = fa_kvcache_append(&p, current_stream(k_new));
     TORCH_CHECK(st == 0, "fa_kvcache_append failed (", st, "): ", fa_strerror(st));
@@ -599,7 +601,8 @@ std::vector<Tensor> fwd_kvcache_impl(Tensor q, const Tensor &kcache, const Tenso
                                      OptTensor cache_batch_idx_, OptTensor leftpad_k_, OptTensor block_table_,
                                      OptTensor alibi_slopes_, OptTensor out_, const double softmax_scale, bool is_causal,
                                      int64_t window_size_left, int64_t window_size_right, const double softcap,
-                                     bool is_rotary_interleaved, int64_t num_splits, int64_t page_multiple) {
+                                     bool is_rotary_interleaved, int64_t num_splits, int64_t page_multiple,
+                                     OptTensor seqlens_rotary_) {
     const auto q_dtype = q.scalar_type();
     TORCH_CHECK(q_dtype == at::kHalf || q_dtype == at::kBFloat16, "FlashAttention only support fp16 and bf16 data type");
     TORCH_CHECK(kcache.scalar_type() == q_dtype, "query and key must have the same dtype");
@@ -706,7 +709,8 @@ std::vector<Tensor> fwd_kvcache_impl(Tensor q, const Tensor &kcache, const Tenso
     OptTensor seqused = seqlens_k_;
     if (seqlen_knew > 0) {  // "Append_KV": new rows land at [seqlens_k, seqlens_k + seqlen_knew) of each cache entry
         const Tensor kn = aligned_or_copy(*k_), vn = aligned_or_copy(*v_);
-        kvcache_append(kn, vn, kcache, vcache, *seqlens_k_, cache_batch_idx_, block_table_, rotary_cos_, rotary_sin_, is_rotary_interleaved);
+        kvcache_append(kn, vn, kcache, vcache, *seqlens_k_, cache_batch_idx_, block_table_, rotary_cos_, rotary_sin_, is_rotary_interleaved,
+                       seqlens_rotary_);
         seqused = *seqlens_k_ + seqlen_knew;
     }
     Tensor qc = aligned_or_copy(q);
@@ -715,7 +719,8 @@ std::vector<Tensor> fwd_kvcache_impl(Tensor q, const Tensor &kcache, const Tenso
         // (flash_attn/flash_attn_interface.py:1516-1524, src/flash_fwd_kernel.h:753-775)
         const bool per_row = is_causal || window_size_left >= 0 || window_size_right >= 0;
         Tensor q_ro = at::empty_like(qc, at::MemoryFormat::Contiguous);
-        rotary_apply(qc, q_ro, *rotary_cos_, *rotary_sin_, *seqlens_k_, is_rotary_interleaved, per_row);
+        rotary_apply(qc, q_ro, *rotary_cos_, *rotary_sin_, seqlens_rotary_.has_value() ? *seqlens_rotary_ : *seqlens_k_,
+                     is_rotary_interleaved, per_row);
         qc = q_ro;
     }
     Tensor oc = aligned(out) ? out : at::empty_like(out, at::MemoryFormat::Contiguous);
@@ -750,7 +755,7 @@ std::vector<Tensor> mha_fwd_kvcache(Tensor &q, const Tensor &kcache, const Tenso
                                     bool is_rotary_interleaved, int64_t num_splits) {
     return fwd_kvcache_impl(q, kcache, vcache, k_, v_, seqlens_k_, rotary_cos_, rotary_sin_, cache_batch_idx_, leftpad_k_,
                             block_table_, alibi_slopes_, out_, softmax_scale, is_causal, window_size_left, window_size_right,
-                            softcap, is_rotary_interleaved, num_splits, 256);  // the reference's page rule (:1265)
+                            softcap, is_rotary_interleaved, num_splits, 256, c10::nullopt);  // the reference's page rule (:1265)
 }
 
 bool set_fa3_window_rule(bool on) {
@@ -768,6 +773,11 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("bwd", &mha_bwd, "Backward pass");
     m.def("varlen_bwd", &mha_varlen_bwd, "Backward pass (variable length)");
     m.def("fwd_kvcache", &mha_fwd_kvcache, "Forward pass, with KV-cache");
-    m.def("_fwd_kvcache_impl", &fwd_kvcache_impl, "fwd_kvcache with the page-size rule of the calling surface");
+    m.def("_fwd_kvcache_impl", &fwd_kvcache_impl, "fwd_kvcache with the page-size rule of the calling surface (+ FA3 seqlens_rotary)",
+          py::arg("q"), py::arg("kcache"), py::arg("vcache"), py::arg("k"), py::arg("v"), py::arg("seqlens_k"), py::arg("rotary_cos"),
+          py::arg("rotary_sin"), py::arg("cache_batch_idx"), py::arg("leftpad_k"), py::arg("block_table"), py::arg("alibi_slopes"),
+          py::arg("out"), py::arg("softmax_scale"), py::arg("is_causal"), py::arg("window_size_left"), py::arg("window_size_right"),
+          py::arg("softcap"), py::arg("is_rotary_interleaved"), py::arg("num_splits"), py::arg("page_multiple"),
+          py::arg("seqlens_rotary") = py::none());
     m.def("_set_fa3_window_rule", &set_fa3_window_rule, "FA3 window rule for the backward entry points (returns the previous value)");
 }

@@ -491,7 +491,8 @@ def _fwd_kvcache_impl(q: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tenso
                 leftpad_k_: Optional[torch.Tensor], block_table_: Optional[torch.Tensor],
                 alibi_slopes_: Optional[torch.Tensor], out_: Optional[torch.Tensor], softmax_scale: float,
                 is_causal: bool, window_size_left: int, window_size_right: int, softcap: float,
-                is_rotary_interleaved: bool, num_splits: int, _page_multiple: int) -> List[torch.Tensor]:
+                is_rotary_interleaved: bool, num_splits: int, _page_multiple: int,
+                seqlens_rotary_: Optional[torch.Tensor] = None) -> List[torch.Tensor]:
     """mha_fwd_kvcache, csrc/flash_attn/flash_api.cpp:1202-1476.  Returns [out, softmax_lse].
 
     Built: in-place append of k_/v_ at seqlens_k_ (keys optionally rotated), attention over the first seqlens_k_
@@ -601,7 +602,7 @@ def _fwd_kvcache_impl(q: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tenso
         if seqlen_knew > 0:  # "Append_KV": new rows land at [seqlens_k, seqlens_k + seqlen_knew) of each cache entry
             kn, vn = (x if _aligned(x) else x.contiguous() for x in (k_, v_))
             _dispatch.kvcache_append(kn, vn, kcache, vcache, seqlens_k_, cache_batch_idx_, block_table_,
-                                     rotary_cos_, rotary_sin_, is_rotary_interleaved)
+                                     rotary_cos_, rotary_sin_, is_rotary_interleaved, seqlens_rotary_)
             seqused = seqlens_k_ + seqlen_knew
         qc = q if _aligned(q) else q.contiguous()
         if rotary:
@@ -609,7 +610,9 @@ def _fwd_kvcache_impl(q: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tenso
             # (flash_attn/flash_attn_interface.py:1516-1524, src/flash_fwd_kernel.h:753-775)
             per_row = is_causal or window_size_left >= 0 or window_size_right >= 0
             q_ro = torch.empty_like(qc, memory_format=torch.contiguous_format)
-            _dispatch.rotary_apply(qc, q_ro, rotary_cos_, rotary_sin_, seqlens_k_, is_rotary_interleaved, per_row)
+            # (FA3 seqlens_rotary: the rotary positions when they are not the cache fill levels, hopper/seqlen.h:89)
+            _dispatch.rotary_apply(qc, q_ro, rotary_cos_, rotary_sin_, seqlens_rotary_ if seqlens_rotary_ is not None else seqlens_k_,
+                                   is_rotary_interleaved, per_row)
             qc = q_ro
         oc = out if _aligned(out) else torch.empty_like(out, memory_format=torch.contiguous_format)
         if seqlen_k > 0:

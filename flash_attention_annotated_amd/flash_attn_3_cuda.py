@@ -38,7 +38,7 @@ def fwd(q, k, v, k_new, v_new, qv, out, cu_seqlens_q, cu_seqlens_k, cu_seqlens_k
     for t, n in ((q, "q"), (k, "k"), (v, "v")):
         _check(t.is_cuda, f"{n} must be on CUDA")
         _check(t.stride(-1) == 1, "Input tensor must have contiguous last dimension")
-    for x, n in ((qv, "qv"), (seqlens_rotary, "seqlens_rotary"), (cu_seqlens_k_new, "cu_seqlens_k_new")):
+    for x, n in ((qv, "qv"), (cu_seqlens_k_new, "cu_seqlens_k_new")):
         _check(x is None, f"This flash attention build does not support {n}.")
     attention_chunk = int(attention_chunk or 0)
     _check(attention_chunk >= 0, "attention_chunk must be non-negative")
@@ -50,6 +50,12 @@ def fwd(q, k, v, k_new, v_new, qv, out, cu_seqlens_q, cu_seqlens_k, cu_seqlens_k
                "or (Q/K <= 64 and V <= 512).")
         _check(not is_fp8, "This flash attention build does not support a V headdim of its own with fp8 inputs.")
         _check(head_size_v % 8 == 0, "head_size_v should be a multiple of 8")  # :856
+    if seqlens_rotary is not None:  # hopper/flash_api.cpp:1074-1079; only read together with k_new + rotary (hopper/seqlen.h:89)
+        _check(seqlens_rotary.is_cuda and seqlens_rotary.is_contiguous(), "seqlens_rotary must be a contiguous CUDA tensor")
+        _check(seqlens_rotary.dtype == torch.int32, "seqlens_rotary must have dtype torch.int32")
+        _check(tuple(seqlens_rotary.shape) == (q.shape[0],), "seqlens_rotary must have shape (batch_size,)")
+        if k_new is None or rotary_cos is None:
+            seqlens_rotary = None
     if any(x is not None for x in (k_new, v_new, page_table, kv_batch_idx, leftpad_k, rotary_cos, rotary_sin)):
         # KV-cache step (hopper/flash_api.cpp:736-760, 935-1060): k / v are the cache, seqused_k its fill levels
         _check(cu_seqlens_q is None and cu_seqlens_k is None and seqused_q is None,
@@ -67,7 +73,7 @@ def fwd(q, k, v, k_new, v_new, qv, out, cu_seqlens_q, cu_seqlens_k, cu_seqlens_k
         o, lse = flash_attn_2_cuda._fwd_kvcache_impl(q, k, v, k_new, v_new, seqused_k, rotary_cos, rotary_sin, kv_batch_idx,
                                                leftpad_k, page_table, None, out, softmax_scale, bool(is_causal),
                                                int(window_size_left), int(window_size_right), float(softcap),
-                                               bool(is_rotary_interleaved), int(num_splits), 1)
+                                               bool(is_rotary_interleaved), int(num_splits), 1, seqlens_rotary)
         return o, lse, None, None
     if (cu_seqlens_q is None and cu_seqlens_k is None and seqused_q is None and seqused_k is not None and not is_fp8
             and q.dim() == 4 and q.shape[1] <= 128 and window_size_left < 0 and (window_size_right < 0 or is_causal)

@@ -259,6 +259,9 @@ typedef struct fa_kvcache_append_params {
     const void *rotary_sin;
     int32_t rotary_dim;
     int32_t rotary_interleaved;
+    /* ABI v12 -- FA3 `seqlens_rotary` (hopper/flash_api.cpp:1074-1079, hopper/seqlen.h:89): (b) int32 rotary position of the
+     * first appended row of each batch entry when it is not the cache fill level; NULL = cache_seqlens. */
+    const int32_t *rotary_seqlens;
 } fa_kvcache_append_params;
 
 int fa_kvcache_append(const fa_kvcache_append_params *params, void *stream);

@@ -109,8 +109,8 @@ def test_fa3_kvcache_rejections():
     q = torch.randn(2, 1, 4, 64, dtype=torch.bfloat16, device=DEV)
     kc = torch.randn(2, 256, 4, 64, dtype=torch.bfloat16, device=DEV)
     lens = torch.tensor([5, 9], dtype=torch.int32, device=DEV)
-    with pytest.raises(RuntimeError, match="does not support seqlens_rotary"):
-        fa3.flash_attn_with_kvcache(q, kc, kc, cache_seqlens=lens, rotary_seqlens=lens)
+    with pytest.raises(RuntimeError, match="seqlens_rotary must have dtype torch.int32"):   # hopper/flash_api.cpp:1077
+        fa3.flash_attn_with_kvcache(q, kc, kc, cache_seqlens=lens, rotary_seqlens=lens.long())
     with pytest.raises(RuntimeError, match="does not support cu_seqlens_k_new"):
         fa3.flash_attn_with_kvcache(q, kc, kc, cache_seqlens=lens, cu_seqlens_k_new=lens)
     with pytest.raises(RuntimeError, match="k_new and v_new must be passed together"):
@@ -154,3 +154,45 @@ def test_fa3_kvcache_any_page_size(sq, d, page, new_kv):
     assert torch.allclose(lse_g, lse_w, atol=1e-5, rtol=1e-6)
     assert torch.equal(kp[table.flatten().long()].reshape(b, sk, hk, d), kc)
     assert torch.equal(vp[table.flatten().long()].reshape(b, sk, hk, d), vc)
+
+
+@pytest.mark.parametrize("interleaved", [False, True])
+@pytest.mark.parametrize("causal", [False, True])
+def test_fa3_rotary_seqlens(causal, interleaved):
+    """`rotary_seqlens` (flash_attn_3::fwd's seqlens_rotary, hopper/flash_api.cpp:1074-1079, hopper/seqlen.h:89): the rotary
+    position of the appended keys and of q is taken from it instead of the cache fill level.  Expected: the oracle on a cache
+    whose new rows were rotated at positions rotary_seqlens + i by apply_rotary_emb_ref, q rotated at rotary_seqlens (+ row
+    under a causal mask)."""
+    fa3 = _fa3()
+    torch.manual_seed(3)
+    b, sq, sk, h, hk, d, rd = 3, 4, 384, 4, 2, 64, 32
+    q = torch.randn(b, sq, h, d, dtype=torch.bfloat16)
+    kc = torch.randn(b, sk, hk, d, dtype=torch.bfloat16)
+    vc = torch.randn(b, sk, hk, d, dtype=torch.bfloat16)
+    kn = torch.randn(b, sq, hk, d, dtype=torch.bfloat16)
+    vn = torch.randn(b, sq, hk, d, dtype=torch.bfloat16)
+    lens = torch.tensor([100, 7, 300], dtype=torch.int32)
+    rot = torch.tensor([20, 333, 0], dtype=torch.int32)   # not the fill levels
+    ang = torch.rand(sk, rd // 2) * 6.28
+    cos, sin = torch.cos(ang).to(torch.bfloat16), torch.sin(ang).to(torch.bfloat16)
+    kcd, vcd = kc.clone().to(DEV), vc.clone().to(DEV)
+    out = fa3.flash_attn_with_kvcache(q.to(DEV), kcd, vcd, kn.to(DEV), vn.to(DEV), rotary_cos=cos.to(DEV), rotary_sin=sin.to(DEV),
+                                      cache_seqlens=lens.to(DEV), rotary_seqlens=rot.to(DEV), causal=causal,
+                                      rotary_interleaved=interleaved)
+    k_rot = oracle.apply_rotary_emb_ref(kn, cos, sin, rot, interleaved=interleaved)
+    q_rot = oracle.apply_rotary_emb_ref(q, cos, sin, rot, interleaved=interleaved, per_row_positions=causal)
+    k_ref, v_ref = kc.clone(), vc.clone()
+    for i in range(b):
+        k_ref[i, int(lens[i]):int(lens[i]) + sq] = k_rot[i]
+        v_ref[i, int(lens[i]):int(lens[i]) + sq] = vn[i]
+    assert torch.equal(kcd.cpu(), k_ref) and torch.equal(vcd.cpu(), v_ref)   # the cache holds the rows rotated at rotary_seqlens
+    mask = torch.arange(sk).view(1, -1) < (lens + sq).view(-1, 1)
+    out_ref, _ = oracle.attention_ref(q_rot, k_ref, v_ref, None, mask, causal=causal)
+    out_pt, _ = oracle.attention_ref(q_rot, k_ref, v_ref, None, mask, causal=causal, upcast=False, reorder_ops=True)
+    err = (out.float().cpu() - out_ref.float()).abs().max().item()
+    assert err <= 3 * (out_pt.float() - out_ref.float()).abs().max().item() + 1e-5
+    # and it differs from the default (positions = fill levels)
+    kcd2, vcd2 = kc.clone().to(DEV), vc.clone().to(DEV)
+    fa3.flash_attn_with_kvcache(q.to(DEV), kcd2, vcd2, kn.to(DEV), vn.to(DEV), rotary_cos=cos.to(DEV), rotary_sin=sin.to(DEV),
+                                cache_seqlens=lens.to(DEV), causal=causal, rotary_interleaved=interleaved)
+    assert not torch.equal(kcd2, kcd)
