@@ -78,7 +78,7 @@ def test_fa3_golden_cases(name, golden_fa3):
 
 @pytest.mark.parametrize("causal,local", [(False, False), (True, False), (False, True)])
 @pytest.mark.parametrize("mha_type", ["gqa"])
-@pytest.mark.parametrize("sq,sk", [(1, 1), (64, 128), (239, 1), (113, 203), (640, 128), (1024, 1023)])
+@pytest.mark.parametrize("sq,sk", [(1, 1), (64, 128), (239, 1), (113, 203), (640, 128), (777, 1023)])
 @pytest.mark.parametrize("d,dtype", [(64, torch.bfloat16), (128, torch.float16), (192, torch.bfloat16)])
 def test_attention_chunk_and_dv_sweep(d, dtype, sq, sk, mha_type, causal, local):
     """The (dv, attention_chunk) loop of hopper/test_flash_attn.py::test_flash_attn_output (:120-200): dv in {128, d} for d in

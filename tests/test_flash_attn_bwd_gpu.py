@@ -315,14 +315,14 @@ def test_attention_modules_match_the_functions():
     assert torch.equal(out, fa.flash_attn_varlen_qkvpacked_func(packed, cu, 100))
 
 
-@pytest.mark.parametrize("d,causal", [(256, True), (192, False)])
+@pytest.mark.parametrize("d,causal", [(256, True)])
 def test_wide_head_dim_grads_long(d, causal):
-    """The head-dim-256 tile's backward over a long sweep (28 key blocks x 47 query tiles per head, GQA 2:1, sq != sk, ragged
+    """The head-dim-256 tile's backward over a long sweep (20 key blocks x 33 query tiles per head, GQA 2:1, sq != sk, ragged
     tails): every workgroup of the dV / dK launches (PART 1 / 2) and of the dQ launch streams dozens of LDS-DMA'd tiles; full
     dq / dk / dv against the oracle's autograd, reference bound (tests/test_flash_attn.py:1129-1132)."""
     fa = _api()
     torch.manual_seed(d)
-    b, sq, sk, h, hk = 1, 2990, 3530, 2, 1
+    b, sq, sk, h, hk = 1, 2090, 2530, 2, 1
     q = torch.randn(b, sq, h, d, dtype=torch.bfloat16)
     k = torch.randn(b, sk, hk, d, dtype=torch.bfloat16)
     v = torch.randn(b, sk, hk, d, dtype=torch.bfloat16)

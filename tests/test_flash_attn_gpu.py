@@ -549,7 +549,7 @@ def test_empty_keys_dense():
     assert torch.all(out == 0) and torch.all(torch.isposinf(lse))
 
 
-@pytest.mark.parametrize("seed", list(range(40)))
+@pytest.mark.parametrize("seed", list(range(24)))
 def test_row_block_kernel_random_sweep(seed):
     """Seeded random problems over everything the 32-row-per-wave kernel (fa_fwd_kernel_d256.h) takes since round 3: head dims
     40 .. 256 with softcap or ALiBi (its DEFF 64 .. 256 forms), head dims 136 .. 256 plain, causal / windows / neither, GQA,
@@ -561,7 +561,7 @@ def test_row_block_kernel_random_sweep(seed):
     feature = ("softcap", "alibi", "plain")[seed % 3]
     d = 8 * ri(17, 32) if feature == "plain" else 8 * ri(5, 32)
     dtype = (torch.bfloat16, torch.float16)[ri(0, 1)]
-    sq, sk = ri(300, 1800), ri(600, 2200)
+    sq, sk = ri(300, 1200), ri(600, 1500)
     if ri(0, 2) == 0:
         sq = sk
     hk = ri(1, 2)
